@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: gate-bootstraps/sec (hom_nand, SECURITY_128_BIT) on N MI355X.
+
+One "step" = one pass of the hot path (fused gate prep + blind rotate, then
+sample-extract + identity key switch) over one batch of synthetic ciphertexts
+per GPU, inputs and keys already resident in HBM.  Workload at N=1 is
+BASELINE.json configs[1]: 65,536 independent hom_nand bootstraps at
+SECURITY_128_BIT; for N>1 every rank runs the same per-GPU batch on its own
+shard (weak scaling, no data-path collective: the path shards embarrassingly).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the driver contract), with two extra objects:
+  roofline     -- dominant kernel (k_blind_rotate) algorithmic bytes / HIP-event duration
+  cpu_baseline -- the oracle (C port of the reference path, OpenMP over ciphertexts =
+                  Rayon par_iter) on this box's host cores, bounded sample (N=1 only)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="ciphertexts per GPU per step")
+    ap.add_argument("--params", default="SECURITY_128_BIT")
+    ap.add_argument("--gate", default="nand")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not launched by torchrun: start it as a child (never exec after touching the GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ncores = os.cpu_count() or 1
+    if world > 1:
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, ncores // world)))
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import rs_tfhe_amd as R
+    from oracle import oracle as O  # harness only: synthetic keys/ciphertexts + cpu_baseline + spot check
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    P = R.params.PARAM_SETS[args.params]
+    OP = O.PARAM_SETS[args.params]
+    gate = R.engine.GATE_IDS[args.gate]
+    B = args.batch
+
+    # ---- synthetic, seeded inputs (identical key on every rank; shards differ by seed) ----
+    t0 = time.time()
+    sk, ock = O.keygen(OP, 2024)
+    rng = np.random.default_rng(1000 + rank)
+    bits_a = rng.integers(0, 2, B).astype(bool)
+    bits_b = rng.integers(0, 2, B).astype(bool)
+    ca = sk.encrypt_bool(bits_a, 11 + 2 * rank)
+    cb = sk.encrypt_bool(bits_b, 12 + 2 * rank)
+    setup_s = time.time() - t0
+
+    ck = R.CloudKey(P, ock.bootstrapping_key, ock.key_switching_key, ock.decomposition_offset,
+                    ock.blind_rotate_testvec)
+    eng = R.Engine(P, local_rank)
+    eng.load_cloud_key(ck)
+    ta = torch.from_numpy(ca.view(np.int32)).to(dev)
+    tb = torch.from_numpy(cb.view(np.int32)).to(dev)
+    to = torch.empty_like(ta)
+
+    def step():
+        eng.batch_gate_dev(gate, ta, tb, to)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_times()  # reset
+    eng.set_profiling(True)  # HIP events around each kernel, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- sanity: decrypt the whole shard (integer, host) ----
+    out = to.cpu().numpy().view(np.uint32)
+    phase = out[:, P.n] - (out[:, :P.n] * sk.key_lv0[None, :]).sum(axis=1, dtype=np.uint32)
+    want = np.array([O.GATE_TRUTH[gate](bool(a), bool(b)) for a, b in zip(bits_a[:4096], bits_b[:4096])])
+    decrypt_ok = bool(np.array_equal(phase.view(np.int32)[:4096] >= 0, want))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    value = world * B * args.steps / elapsed
+    bytes_per_bootstrap = P.algorithmic_bytes_per_bootstrap(2)
+    # dominant kernel: k_blind_rotate.  Algorithmic bytes per launch = B * (BSK once +
+    # two input TLWEs + the extracted level-1 TLWE it writes)  (DESIGN.md "Roofline accounting")
+    br_bytes_per_ct = P.bsk_bytes + 2 * P.tlwe_lv0_bytes + (R.params.N + 1) * 4
+    br_ms = kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"])
+    ks_ms = kt["key_switch_ms"] / max(1, kt["key_switch_launches"])
+    achieved = (br_bytes_per_ct * B) / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+    roofline = {
+        "kernel": "k_blind_rotate<3>",
+        "bound": "hbm",
+        "achieved": round(achieved, 1),
+        "peak": 8000.0,
+        "unit": "GB/s",
+        "frac": round(achieved / 8000.0, 4),
+        "traffic": None,
+        "algorithmic_bytes_per_launch": br_bytes_per_ct * B,
+        "avg_launch_ms": round(br_ms, 3),
+        "key_switch_avg_launch_ms": round(ks_ms, 3),
+        "whole_path_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
+        "whole_path_frac": round(value / world * bytes_per_bootstrap / 8e12, 4),
+    }
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        threads = O.num_threads()
+        # calibrate on one ciphertext per thread, then size the sample for ~cpu_seconds
+        t1 = time.perf_counter()
+        O.batch_gate(ock, gate, ca[:threads], cb[:threads])
+        per = max(1e-3, time.perf_counter() - t1)
+        sample = int(min(B, max(threads, threads * int(args.cpu_seconds / per))))
+        t1 = time.perf_counter()
+        ref = O.batch_gate(ock, gate, ca[:sample], cb[:sample])
+        cpu_s = time.perf_counter() - t1
+        cpu = {
+            "value": round(sample / cpu_s, 2),
+            "unit": "bootstraps/s",
+            "cores": threads,
+            "kind": "port",
+            "sample": f"{sample} of the same {args.gate} batch ({args.params}), OpenMP over ciphertexts, {cpu_s:.1f} s",
+            "gpu_matches_cpu_bit_exact": bool(np.array_equal(ref, out[:sample])),
+        }
+
+    line = {
+        "metric": f"gate-bootstraps/sec (hom_{args.gate}, {args.params})",
+        "value": round(value, 1),
+        "unit": "bootstraps/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"batch of {B} independent hom_{args.gate} bootstraps per GPU, {args.params} (N=1024)",
+            "batch_per_gpu": B,
+            "global_batch": B * world,
+            "parallelism": f"batch-sharded x{world}, one process per GPU, no data-path collective",
+            "n": P.n, "l": P.l, "bgbit": P.bgbit, "basebit": P.basebit, "t": P.iks_t,
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "decrypt_ok": decrypt_ok,
+        "setup_s": round(setup_s, 1),
+    }
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

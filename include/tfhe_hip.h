@@ -1,0 +1,209 @@
+/*
+ * tfhe_hip.h -- C ABI of the MI355X (gfx950) TFHE gate-bootstrapping engine.
+ *
+ * This is the drop-in boundary for the hot path of thedonutfactory/rs-tfhe:
+ *   gate linear prep -> blind rotation -> sample extract -> identity key switch.
+ * Conventions follow the reference's only existing FFI, the SPQLIOS wrapper
+ * (src/fft/spqlios/spqlios-wrapper.cpp:10-41, Rust decls spqlios_fft.rs:23-34):
+ * opaque handle from *_create, freed by *_destroy; caller-owned, caller-allocated
+ * flat u32 / f64 buffers passed as raw pointers; no callbacks, no torch types.
+ *
+ * Each entry point names the reference interface it replaces (paths relative
+ * to the rs-tfhe repository root).  The reference has no Result on this path
+ * (failure = panic); here every function returns 0 on success or a negative
+ * TFHE_HIP_E* code, with tfhe_hip_last_error() giving the text.  A binding that
+ * wants the reference's infallible signatures `expect()`s the code.
+ *
+ * Layouts crossing the boundary (all row-major, little-endian):
+ *   TLWELv0     [n+1]  u32      (src/tlwe.rs:12-14)       p[0..n]=a, p[n]=b
+ *   TLWELv1     [N+1]  u32      (src/tlwe.rs:217-219)
+ *   TRLWELv1    [2][N] u32      (src/trlwe.rs:11-14)      a then b
+ *   TRGSWLv1FFT [2l][2][N] f64  (src/trgsw.rs:53-55, src/trlwe.rs:85-88)
+ *                                each [N] = re[0..N/2] || im[0..N/2] as produced
+ *                                by KlemsaProcessor::ifft (src/fft/klemsa.rs:88-117)
+ *   bootstrapping_key  [n] TRGSWLv1FFT                     (src/key.rs:51-56)
+ *   key_switching_key  [N][t][base][n+1] u32, index base*t*i + base*j + k
+ *                                                          (src/key.rs:102-122)
+ * N = 1024 in every parameter set of the reference (src/params.rs).
+ *
+ * Pointers are HOST pointers unless the function name ends in _dev, in which
+ * case they are device pointers on the context's GPU and the call is enqueued
+ * on `stream` (a hipStream_t passed as void*; NULL = the context's own stream)
+ * without synchronising.
+ *
+ * Thread safety: a context may be used from several host threads (the
+ * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23); calls on one
+ * context are serialised internally.
+ */
+#ifndef TFHE_HIP_H
+#define TFHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TFHE_HIP_N 1024
+
+/* error codes */
+#define TFHE_HIP_OK 0
+#define TFHE_HIP_EINVAL (-1)  /* bad argument / unsupported parameter set */
+#define TFHE_HIP_EHIP (-2)    /* a HIP runtime call failed               */
+#define TFHE_HIP_ENOKEY (-3)  /* cloud key not loaded                     */
+#define TFHE_HIP_ENOMEM (-4)
+
+/* Run-time form of SecurityParams / TrgswParams (src/params.rs:53-84). */
+typedef struct tfhe_hip_params {
+  int32_t n;       /* tlwe_lv0.n   (<= 2047)            */
+  int32_t l;       /* trgsw_lv1.l  (1..3)               */
+  int32_t bgbit;   /* trgsw_lv1.bgbit (l*bgbit <= 32)   */
+  int32_t basebit; /* trgsw_lv1.basebit                 */
+  int32_t t;       /* trgsw_lv1.iks_t (basebit*t <= 31) */
+} tfhe_hip_params;
+
+/* Gate selector for tfhe_hip_batch_gate*: the linear prep of src/gates.rs:54-150. */
+typedef enum tfhe_hip_gate {
+  TFHE_HIP_NAND = 0,   /* gates.rs:54-58   -(a+b), b += 1/8  */
+  TFHE_HIP_OR = 1,     /* gates.rs:62-66    a+b,   b += 1/8  */
+  TFHE_HIP_AND = 2,    /* gates.rs:70-74    a+b,   b -= 1/8  */
+  TFHE_HIP_XOR = 3,    /* gates.rs:78-82    a+2b,  b += 1/4  */
+  TFHE_HIP_XNOR = 4,   /* gates.rs:86-90    a-2b,  b -= 1/4  */
+  TFHE_HIP_NOR = 5,    /* gates.rs:94-98   -(a+b), b -= 1/8  */
+  TFHE_HIP_ANDNY = 6,  /* gates.rs:102-111 -a+b,   b -= 1/8  */
+  TFHE_HIP_ANDYN = 7,  /* gates.rs:115-124  a-b,   b -= 1/8  */
+  TFHE_HIP_ORNY = 8,   /* gates.rs:128-137 -a+b,   b += 1/8  */
+  TFHE_HIP_ORYN = 9,   /* gates.rs:141-150  a-b,   b += 1/8  */
+  TFHE_HIP_COPY = 10   /* no prep: plain bootstrap of a (vanilla.rs:40-52) */
+} tfhe_hip_gate;
+
+typedef struct tfhe_hip_ctx tfhe_hip_ctx;
+
+/* ---- lifetime ---------------------------------------------------------- */
+
+/* Replaces: FFT_PLAN thread-local construction (src/fft/mod.rs:47-61) and the
+ * SPQLIOS precedent Spqlios_new (spqlios-wrapper.cpp:10-13).
+ * `device` is the HIP device ordinal this context owns (one context per GPU;
+ * one process per GPU under torch.distributed). */
+int tfhe_hip_ctx_create(const tfhe_hip_params *params, int device, tfhe_hip_ctx **out);
+
+/* Replaces: Drop for SpqliosFFT (spqlios_fft.rs:84-90). NULL is a no-op. */
+void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx);
+
+/* Text of the last error on this context (or of the last failed create when
+ * ctx == NULL).  Never NULL. */
+const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx);
+
+/* "MI355X-native HIP (gfx950)" style identification: Bootstrap::name()
+ * (src/bootstrap/mod.rs:37) of the strategy this library backs. */
+const char *tfhe_hip_name(void);
+
+/* ---- cloud key --------------------------------------------------------- */
+
+/* Replaces: borrowing `&CloudKey` on every call (src/key.rs:51-56).  Uploads
+ * and converts the key once; host buffers may be freed on return.
+ *   bsk            [n][2l][2][N] f64, reference Klemsa spectral layout
+ *   ksk            [N][t][base][n+1] u32 (k = 0 slots are ignored)
+ *   decomp_offset  CloudKey::decomposition_offset (key.rs:78-89)
+ *   testvec        CloudKey::blind_rotate_testvec [2][N] (key.rs:91-100) */
+int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
+                            uint32_t decomp_offset, const uint32_t *testvec);
+
+/* ---- the hot path, batched --------------------------------------------- */
+
+/* Replaces: gates::batch_{nand,and,or,xor,nor,xnor}[_with_railgun]
+ * (src/gates.rs:352-547) and, with count == 1, Gates::{nand,...,or_yn}
+ * (src/gates.rs:54-150).  a, b, out: [count][n+1].  b is ignored for COPY. */
+int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
+                        uint32_t *out, size_t count);
+int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
+                            uint32_t *out, size_t count, void *stream);
+
+/* Replaces: Bootstrap::bootstrap / bootstrap_without_key_switch
+ * (src/bootstrap/vanilla.rs:40-63) and LutBootstrap::bootstrap_lut
+ * (src/bootstrap/lut.rs:79-99), mapped over a batch.
+ *   in        [count][n+1]
+ *   testvec   NULL = the cloud key's test vector; else a LookupTable.poly
+ *             ([2][N], shared by the batch) or [count][2][N] when per_ct != 0
+ *   keyswitch 1: sample_extract_index(.,0) + identity_key_switching
+ *             0: sample_extract_index_2(.,0)  (vanilla.rs:54-63)
+ *   out       [count][n+1] */
+int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                             int per_ct, int keyswitch, uint32_t *out, size_t count);
+int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                                 int per_ct, int keyswitch, uint32_t *out, size_t count,
+                                 void *stream);
+
+/* Replaces: trgsw::batch_blind_rotate[_with_railgun] (src/trgsw.rs:289-305),
+ * trgsw::blind_rotate (:198-226) and blind_rotate_with_testvec (:242-274).
+ * in [count][n+1]; testvec NULL or [2][N]; out_trlwe [count][2][N]. */
+int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                                uint32_t *out_trlwe, size_t count);
+int tfhe_hip_batch_blind_rotate_dev(tfhe_hip_ctx *ctx, const uint32_t *in,
+                                    const uint32_t *testvec, uint32_t *out_trlwe, size_t count,
+                                    void *stream);
+
+/* Replaces: Gates::mux (src/gates.rs:157-183, naive == 0; the reference
+ * formula reproduced bit-for-bit) and Gates::mux_naive
+ * (src/gates.rs:189-199, naive != 0), mapped over a batch.  [count][n+1] each. */
+int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
+                       const uint32_t *c, uint32_t *out, size_t count);
+int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
+                           const uint32_t *c, uint32_t *out, size_t count, void *stream);
+
+/* ---- single stages (parity tests; same kernels' device code) ------------ */
+
+/* Replaces: trgsw::external_product_with_fft (src/trgsw.rs:77-116) with
+ * trgsw_fft = cloud_key.bootstrapping_key[bsk_index[c]].
+ * trlwe_in/out [count][2][N]; bsk_index [count]. */
+int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
+                                    const int32_t *bsk_index, uint32_t *trlwe_out, size_t count);
+
+/* Replaces: trlwe::sample_extract_index(.,0) (src/trlwe.rs:106-120).
+ * trlwe [count][2][N] -> out [count][N+1]. */
+int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, uint32_t *out,
+                                  size_t count);
+
+/* Replaces: trgsw::identity_key_switching (src/trgsw.rs:332-360).
+ * tlwe_lv1 [count][N+1] -> out [count][n+1]. */
+int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_lv1,
+                                       uint32_t *out, size_t count);
+
+/* Replaces: FFTProcessor::{ifft, fft, poly_mul, batch_ifft, batch_fft}
+ * (src/fft/mod.rs:80-107; KlemsaProcessor src/fft/klemsa.rs:88-174) and the
+ * SPQLIOS C ABI Spqlios_ifft_lv1 / _fft_lv1 / _poly_mul_1024
+ * (spqlios-wrapper.cpp:19-40).  Spectra use the Klemsa layout and scaling.
+ *   ifft:     src [count][N] u32 -> res [count][N] f64
+ *   fft:      src [count][N] f64 -> res [count][N] u32
+ *   poly_mul: a, b [count][N] u32 -> res [count][N] u32  (negacyclic) */
+int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, size_t count);
+int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size_t count);
+int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
+                            const uint32_t *b, size_t count);
+
+/* ---- measurement -------------------------------------------------------- */
+
+/* When enabled, every blind-rotate / key-switch launch is bracketed by HIP
+ * events on the stream it is launched on. */
+int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled);
+
+typedef struct tfhe_hip_kernel_times {
+  double blind_rotate_ms; /* sum of blind-rotate kernel durations       */
+  double key_switch_ms;   /* sum of key-switch kernel durations         */
+  uint64_t blind_rotate_launches;
+  uint64_t key_switch_launches;
+  uint64_t bootstraps;    /* ciphertexts that went through blind rotate */
+} tfhe_hip_kernel_times;
+
+/* Synchronises the recorded events, returns the sums since the last reset and
+ * resets them. */
+int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out);
+
+/* Block until everything enqueued on the context's own stream has finished. */
+int tfhe_hip_synchronize(tfhe_hip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TFHE_HIP_H */

@@ -85,13 +85,16 @@ PARAM_SETS = {p.name: p for p in (SECURITY_80_BIT, SECURITY_110_BIT, SECURITY_12
 # gate op codes -- shared with include/tfhe_hip.h
 GATE_NAND, GATE_OR, GATE_AND, GATE_XOR, GATE_XNOR, GATE_NOR, GATE_ANDNY, GATE_ANDYN, GATE_ORNY, GATE_ORYN, GATE_COPY = range(11)
 GATE_NAMES = ["nand", "or", "and", "xor", "xnor", "nor", "and_ny", "and_yn", "or_ny", "or_yn", "copy"]
-# plaintext truth functions of the reference gates (gates.rs:54-150)
+# plaintext truth functions of the reference gates (gates.rs:54-150), as the reference's own
+# unit tests assert them (gates.rs:559-653).  NB quirk Q8: Gates::xnor = a - 2b - 1/4 decrypts
+# to XOR, and the reference's test_hom_xnor asserts exactly that (`false ^ (b ^ a)`,
+# gates.rs:576-582) -- reproduced, not "fixed".
 GATE_TRUTH = {
     GATE_NAND: lambda a, b: not (a and b),
     GATE_OR: lambda a, b: a or b,
     GATE_AND: lambda a, b: a and b,
     GATE_XOR: lambda a, b: a != b,
-    GATE_XNOR: lambda a, b: a == b,
+    GATE_XNOR: lambda a, b: False ^ (b ^ a),
     GATE_NOR: lambda a, b: not (a or b),
     GATE_ANDNY: lambda a, b: (not a) and b,
     GATE_ANDYN: lambda a, b: a and (not b),

@@ -1,0 +1,95 @@
+"""ctypes binding of the C ABI declared in include/tfhe_hip.h.
+
+The product path has no CPU fallback: if libtfhe_hip.so is missing or cannot
+be loaded this module raises, it never routes anywhere else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtfhe_hip.so")
+
+OK, EINVAL, EHIP, ENOKEY, ENOMEM = 0, -1, -2, -3, -4
+
+
+class TfheHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"tfhe_hip error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    """struct tfhe_hip_params"""
+
+    _fields_ = [("n", C.c_int32), ("l", C.c_int32), ("bgbit", C.c_int32), ("basebit", C.c_int32), ("t", C.c_int32)]
+
+
+class KernelTimes(C.Structure):
+    """struct tfhe_hip_kernel_times"""
+
+    _fields_ = [
+        ("blind_rotate_ms", C.c_double),
+        ("key_switch_ms", C.c_double),
+        ("blind_rotate_launches", C.c_uint64),
+        ("key_switch_launches", C.c_uint64),
+        ("bootstraps", C.c_uint64),
+    ]
+
+
+_P = C.c_void_p
+_SZ = C.c_size_t
+_CTX = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/tfhe_hip.h declares
+SIGNATURES = {
+    "tfhe_hip_ctx_create": (C.c_int, [C.POINTER(Params), C.c_int, C.POINTER(_CTX)]),
+    "tfhe_hip_ctx_destroy": (None, [_CTX]),
+    "tfhe_hip_last_error": (C.c_char_p, [_CTX]),
+    "tfhe_hip_name": (C.c_char_p, []),
+    "tfhe_hip_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
+    "tfhe_hip_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_batch_bootstrap": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ]),
+    "tfhe_hip_batch_bootstrap_dev": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ, _P]),
+    "tfhe_hip_batch_blind_rotate": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_blind_rotate_dev": (C.c_int, [_CTX, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_batch_mux": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_mux_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_batch_external_product": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_sample_extract": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_identity_key_switch": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_ifft": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_fft": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_poly_mul": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
+    "tfhe_hip_set_profiling": (C.c_int, [_CTX, C.c_int]),
+    "tfhe_hip_get_kernel_times": (C.c_int, [_CTX, C.POINTER(KernelTimes)]),
+    "tfhe_hip_synchronize": (C.c_int, [_CTX]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libtfhe_hip.so (built in-tree by __graft_entry__.build / csrc/Makefile)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `make -C rs-tfhe_amd/csrc` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback."
+            )
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(ctx, rc: int) -> None:
+    if rc != OK:
+        msg = lib().tfhe_hip_last_error(ctx)
+        raise TfheHipError(rc, msg.decode() if msg else "")

@@ -1,0 +1,668 @@
+// tfhe_hip.hip -- C ABI (include/tfhe_hip.h) over the gfx950 kernels.
+//
+// Host side of the engine: context (device, stream, converted cloud key,
+// scratch), launch geometry, and the batched entry points that compose
+//   gate prep + blind rotate (one persistent kernel)  ->  key switch (one kernel)
+// exactly as gates::batch_* composes them in the reference
+// (src/gates.rs:357-383: prepare, batch_blind_rotate, extract + key switch).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tfhe_hip.h"
+#include "blind_rotate.hpp"
+#include "key_switch.hpp"
+
+using namespace tfhe;
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+constexpr int kKsG = 8;  // ciphertexts per key-switch workgroup
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct tfhe_hip_ctx {
+  tfhe_hip_params P{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double2 *d_bsk = nullptr;
+  uint32_t *d_ksk = nullptr;
+  uint32_t *d_testvec = nullptr;
+  double2 *d_tw = nullptr;
+  uint32_t offset = 0;
+  bool key_loaded = false;
+  DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx;  // scratch / host-API staging
+  std::mutex mu;
+  std::string err = "";
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
+  uint64_t bootstraps = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess) {                                                                 \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      return TFHE_HIP_EHIP;                                                                 \
+    }                                                                                       \
+  } while (0)
+
+#define CHK(expr)                 \
+  do {                            \
+    int rc_ = (expr);             \
+    if (rc_ != TFHE_HIP_OK) return rc_; \
+  } while (0)
+
+namespace {
+
+int fail(tfhe_hip_ctx *ctx, int code, const std::string &msg) {
+  ctx->err = msg;
+  return code;
+}
+
+int ensure(tfhe_hip_ctx *ctx, DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return TFHE_HIP_OK;
+  if (b.p) HIPCHK(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = bytes + bytes / 4;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    ctx->err = std::string("hipMalloc scratch: ") + hipGetErrorString(e);
+    return TFHE_HIP_ENOMEM;
+  }
+  b.cap = want;
+  return TFHE_HIP_OK;
+}
+
+struct GatePrep {
+  uint32_t ca, cb, cconst;
+};
+
+// src/gates.rs:54-150; constants are utils::f64_to_torus(+-0.125 / +-0.25) (utils.rs:9-12)
+bool gate_prep(int gate, GatePrep &g) {
+  const uint32_t P8 = 0x20000000u, M8 = 0xE0000000u, P4 = 0x40000000u, M4 = 0xC0000000u;
+  const uint32_t ONE = 1u, NEG = 0xFFFFFFFFu, TWO = 2u, NEG2 = 0xFFFFFFFEu;
+  switch (gate) {
+    case TFHE_HIP_NAND: g = {NEG, NEG, P8}; return true;
+    case TFHE_HIP_OR: g = {ONE, ONE, P8}; return true;
+    case TFHE_HIP_AND: g = {ONE, ONE, M8}; return true;
+    case TFHE_HIP_XOR: g = {ONE, TWO, P4}; return true;
+    case TFHE_HIP_XNOR: g = {ONE, NEG2, M4}; return true;
+    case TFHE_HIP_NOR: g = {NEG, NEG, M8}; return true;
+    case TFHE_HIP_ANDNY: g = {NEG, ONE, M8}; return true;
+    case TFHE_HIP_ANDYN: g = {ONE, NEG, M8}; return true;
+    case TFHE_HIP_ORNY: g = {NEG, ONE, P8}; return true;
+    case TFHE_HIP_ORYN: g = {ONE, NEG, P8}; return true;
+    case TFHE_HIP_COPY: g = {ONE, 0u, 0u}; return true;
+    default: return false;
+  }
+}
+
+int record_begin(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+  if (!ctx->profiling) return TFHE_HIP_OK;
+  hipEvent_t a, b;
+  HIPCHK(ctx, hipEventCreate(&a));
+  HIPCHK(ctx, hipEventCreate(&b));
+  HIPCHK(ctx, hipEventRecord(a, s));
+  v.emplace_back(a, b);
+  return TFHE_HIP_OK;
+}
+
+int record_end(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_t, hipEvent_t>> &v) {
+  if (!ctx->profiling) return TFHE_HIP_OK;
+  HIPCHK(ctx, hipEventRecord(v.back().second, s));
+  return TFHE_HIP_OK;
+}
+
+size_t br_lds_bytes(const tfhe_hip_ctx *ctx) {
+  size_t b = kTileBytes + (size_t)ctx->P.n * 2;
+  return (b + 15) & ~(size_t)15;
+}
+
+int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, const uint32_t *in_b,
+                        GatePrep gp, const uint32_t *testvec, int per_ct, size_t count,
+                        uint32_t *out_trlwe, uint32_t *out_lv1, uint32_t *out_ext2) {
+  if (count == 0) return TFHE_HIP_OK;
+  if (count > 0x7FFFFFFFull) return fail(ctx, TFHE_HIP_EINVAL, "count too large");
+  BlindRotateArgs A;
+  A.in_a = in_a;
+  A.in_b = gp.cb ? in_b : nullptr;
+  A.ca = gp.ca;
+  A.cb = gp.cb;
+  A.cconst = gp.cconst;
+  A.testvec = testvec ? testvec : ctx->d_testvec;
+  A.per_ct_stride = (testvec && per_ct) ? (size_t)2 * kN : 0;
+  A.bsk = ctx->d_bsk;
+  A.tw = ctx->d_tw;
+  A.n = ctx->P.n;
+  A.bgbit = ctx->P.bgbit;
+  A.offset = ctx->offset;
+  A.out_trlwe = out_trlwe;
+  A.out_lv1 = out_lv1;
+  A.out_ext2 = out_ext2;
+  if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
+  dim3 grid((unsigned)count), block(64);
+  size_t lds = br_lds_bytes(ctx);
+  CHK(record_begin(ctx, s, ctx->ev_br));
+  switch (ctx->P.l) {
+    case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, lds, s, A); break;
+    case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, lds, s, A); break;
+    case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, lds, s, A); break;
+    default: return fail(ctx, TFHE_HIP_EINVAL, "unsupported l");
+  }
+  HIPCHK(ctx, hipGetLastError());
+  CHK(record_end(ctx, s, ctx->ev_br));
+  ctx->bootstraps += count;
+  return TFHE_HIP_OK;
+}
+
+int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
+  if (count == 0) return TFHE_HIP_OK;
+  const int n = ctx->P.n;
+  const int xc = (n + 1 > 1024) ? 2 : 1;
+  int bd = ((n + 1 + xc - 1) / xc + 63) & ~63;
+  dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
+  size_t lds = (size_t)kKsG * kN * sizeof(uint32_t);
+  CHK(record_begin(ctx, s, ctx->ev_ks));
+  if (xc == 1)
+    hipLaunchKernelGGL((k_key_switch<kKsG, 1>), grid, block, lds, s, lv1, ctx->d_ksk, n, ctx->P.basebit,
+                       ctx->P.t, out, count);
+  else
+    hipLaunchKernelGGL((k_key_switch<kKsG, 2>), grid, block, lds, s, lv1, ctx->d_ksk, n, ctx->P.basebit,
+                       ctx->P.t, out, count);
+  HIPCHK(ctx, hipGetLastError());
+  CHK(record_end(ctx, s, ctx->ev_ks));
+  return TFHE_HIP_OK;
+}
+
+int need_key(tfhe_hip_ctx *ctx) {
+  if (!ctx->key_loaded) return fail(ctx, TFHE_HIP_ENOKEY, "cloud key not loaded");
+  return TFHE_HIP_OK;
+}
+
+hipStream_t pick(tfhe_hip_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
+
+// ---- device-pointer implementations (mutex held by caller) -------------------
+
+int gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
+             size_t count, hipStream_t s) {
+  GatePrep gp;
+  if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
+  CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+  CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
+  return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
+}
+
+int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec, int per_ct,
+                  int keyswitch, uint32_t *out, size_t count, hipStream_t s) {
+  GatePrep gp;
+  gate_prep(TFHE_HIP_COPY, gp);
+  if (keyswitch) {
+    CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+    CHK(launch_blind_rotate(ctx, s, in, nullptr, gp, testvec, per_ct, count, nullptr,
+                            (uint32_t *)ctx->lv1.p, nullptr));
+    return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
+  }
+  return launch_blind_rotate(ctx, s, in, nullptr, gp, testvec, per_ct, count, nullptr, nullptr, out);
+}
+
+int mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c,
+            uint32_t *out, size_t count, hipStream_t s) {
+  const size_t ctb = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(ensure(ctx, ctx->u1, ctb));
+  CHK(ensure(ctx, ctx->u2, ctb));
+  uint32_t *u1 = (uint32_t *)ctx->u1.p, *u2 = (uint32_t *)ctx->u2.p;
+  GatePrep g_and, g_andny, g_or;
+  gate_prep(TFHE_HIP_AND, g_and);
+  gate_prep(TFHE_HIP_ANDNY, g_andny);  // and(not(a), c) = -a + c - 1/8  (gates.rs:172-175, 196-197)
+  gate_prep(TFHE_HIP_OR, g_or);
+  if (naive) {  // gates.rs:189-199
+    CHK(gate_dev(ctx, TFHE_HIP_AND, a, b, u1, count, s));
+    CHK(gate_dev(ctx, TFHE_HIP_ANDNY, a, c, u2, count, s));
+    return gate_dev(ctx, TFHE_HIP_OR, u1, u2, out, count, s);
+  }
+  // gates.rs:157-183: two bootstrap_without_key_switch, add, one full bootstrap
+  CHK(launch_blind_rotate(ctx, s, a, b, g_and, nullptr, 0, count, nullptr, nullptr, u1));
+  CHK(launch_blind_rotate(ctx, s, a, c, g_andny, nullptr, 0, count, nullptr, nullptr, u2));
+  return gate_dev(ctx, TFHE_HIP_OR, u1, u2, out, count, s);
+}
+
+// host staging helpers
+int to_dev(tfhe_hip_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
+  CHK(ensure(ctx, b, bytes));
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return TFHE_HIP_OK;
+}
+
+int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
+  HIPCHK(ctx, hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_HIP_OK;
+}
+
+void make_twiddles(std::vector<double2> &tw) {
+  tw.resize(576);
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (int k1 = 0; k1 < 8; ++k1)
+    for (int l = 0; l < 64; ++l) {
+      // T1[l][k1] = exp(i*pi*l*(1-4*k1)/1024)
+      long e = ((long)l * (1 - 4 * k1)) % 2048;
+      if (e < 0) e += 2048;
+      long double ang = pi * (long double)e / 1024.0L;
+      tw[k1 * 64 + l] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+  for (int k2 = 0; k2 < 8; ++k2)
+    for (int l1 = 0; l1 < 8; ++l1) {
+      // T2[l1][k2] = exp(-2*pi*i*l1*k2/64)
+      int e = (l1 * k2) % 64;
+      long double ang = -2.0L * pi * (long double)e / 64.0L;
+      tw[512 + k2 * 8 + l1] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+}
+
+}  // namespace
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+const char *tfhe_hip_name(void) { return "hip-gfx950"; }
+
+const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out) {
+  if (!p || !out) {
+    g_create_error = "null argument";
+    return TFHE_HIP_EINVAL;
+  }
+  *out = nullptr;
+  if (p->n < 1 || p->n > 2047 || p->l < 1 || p->l > 3 || p->bgbit < 1 || p->l * p->bgbit > 32 ||
+      p->basebit < 1 || p->basebit > 10 || p->t < 1 || p->basebit * p->t > 31) {
+    g_create_error = "unsupported parameter set";
+    return TFHE_HIP_EINVAL;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return TFHE_HIP_EHIP;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_error = "device ordinal out of range";
+    return TFHE_HIP_EINVAL;
+  }
+  tfhe_hip_ctx *ctx = new tfhe_hip_ctx();
+  ctx->P = *p;
+  ctx->device = device;
+  auto bail = [&](const char *what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    delete ctx;
+    return TFHE_HIP_EHIP;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+    return bail("hipStreamCreate", e);
+  std::vector<double2> tw;
+  make_twiddles(tw);
+  if ((e = hipMalloc((void **)&ctx->d_tw, tw.size() * sizeof(double2))) != hipSuccess)
+    return bail("hipMalloc twiddles", e);
+  if ((e = hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
+    return bail("hipMemcpy twiddles", e);
+  // the persistent kernel may want > 64 KiB of dynamic LDS only for absurd n; the
+  // default limit (64 KiB) is ample: 9216 + 2n bytes.
+  *out = ctx;
+  return TFHE_HIP_OK;
+}
+
+void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->ev_br) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  for (auto &p : ctx->ev_ks) {
+    (void)hipEventDestroy(p.first);
+    (void)hipEventDestroy(p.second);
+  }
+  DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx};
+  for (DevBuf *b : bufs)
+    if (b->p) (void)hipFree(b->p);
+  if (ctx->d_bsk) (void)hipFree(ctx->d_bsk);
+  if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
+  if (ctx->d_testvec) (void)hipFree(ctx->d_testvec);
+  if (ctx->d_tw) (void)hipFree(ctx->d_tw);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
+                            uint32_t decomp_offset, const uint32_t *testvec) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!bsk || !ksk || !testvec) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const tfhe_hip_params &P = ctx->P;
+  const size_t polys = (size_t)P.n * 2 * P.l * 2;
+  const size_t bsk_bytes = polys * kN * sizeof(double);
+  const int base = 1 << P.basebit;
+  const size_t ksk_words = (size_t)kN * P.t * base * (size_t)(P.n + 1);
+  ctx->key_loaded = false;
+  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bsk_bytes));
+  if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, ksk_words * 4));
+  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
+  // bootstrapping key: upload the reference layout, permute + scale on the device
+  double *d_ref = nullptr;
+  HIPCHK(ctx, hipMalloc((void **)&d_ref, bsk_bytes));
+  hipError_t e = hipMemcpyAsync(d_ref, bsk, bsk_bytes, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_bsk_convert, dim3((unsigned)polys), dim3(512), 0, ctx->stream, d_ref, ctx->d_bsk, polys);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ref);
+  if (e != hipSuccess) return fail(ctx, TFHE_HIP_EHIP, std::string("bsk upload: ") + hipGetErrorString(e));
+  // key-switching key: reference layout, k == 0 rows forced to zero
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_ksk, ksk, ksk_words * 4, hipMemcpyHostToDevice, ctx->stream));
+  const size_t groups = (size_t)kN * P.t;
+  hipLaunchKernelGGL(k_ksk_zero_k0, dim3((unsigned)groups), dim3(256), 0, ctx->stream, ctx->d_ksk, P.n, base, groups);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, testvec, 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->offset = decomp_offset;
+  ctx->key_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+// ---- device-pointer entry points ---------------------------------------------
+
+int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
+                            uint32_t *out, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!a || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return gate_dev(ctx, gate, a, b, out, count, pick(ctx, stream));
+}
+
+int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                                 int per_ct, int keyswitch, uint32_t *out, size_t count,
+                                 void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!in || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return bootstrap_dev(ctx, in, testvec, per_ct, keyswitch, out, count, pick(ctx, stream));
+}
+
+int tfhe_hip_batch_blind_rotate_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                                    uint32_t *out_trlwe, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!in || !out_trlwe)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  GatePrep gp;
+  gate_prep(TFHE_HIP_COPY, gp);
+  return launch_blind_rotate(ctx, pick(ctx, stream), in, nullptr, gp, testvec, 0, count, out_trlwe,
+                             nullptr, nullptr);
+}
+
+int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
+                           const uint32_t *c, uint32_t *out, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!a || !b || !c || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return mux_dev(ctx, naive, a, b, c, out, count, pick(ctx, stream));
+}
+
+// ---- host-pointer entry points -----------------------------------------------
+
+int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
+                        uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  GatePrep gp;
+  if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
+  if (!a || !out || (gp.cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  if (gp.cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(gate_dev(ctx, gate, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p, (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                             int per_ct, int keyswitch, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!in || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, in, bytes));
+  const uint32_t *d_tv = nullptr;
+  if (testvec) {
+    CHK(to_dev(ctx, ctx->h_tv, testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4));
+    d_tv = (const uint32_t *)ctx->h_tv.p;
+  }
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(bootstrap_dev(ctx, (uint32_t *)ctx->h_a.p, d_tv, per_ct, keyswitch, (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
+                                uint32_t *out_trlwe, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!in || !out_trlwe) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CHK(to_dev(ctx, ctx->h_a, in, count * (size_t)(ctx->P.n + 1) * 4));
+  const uint32_t *d_tv = nullptr;
+  if (testvec) {
+    CHK(to_dev(ctx, ctx->h_tv, testvec, (size_t)2 * kN * 4));
+    d_tv = (const uint32_t *)ctx->h_tv.p;
+  }
+  const size_t obytes = count * (size_t)2 * kN * 4;
+  CHK(ensure(ctx, ctx->h_out, obytes));
+  GatePrep gp;
+  gate_prep(TFHE_HIP_COPY, gp);
+  CHK(launch_blind_rotate(ctx, ctx->stream, (uint32_t *)ctx->h_a.p, nullptr, gp, d_tv, 0, count,
+                          (uint32_t *)ctx->h_out.p, nullptr, nullptr));
+  return to_host(ctx, out_trlwe, ctx->h_out, obytes);
+}
+
+int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
+                       const uint32_t *c, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!a || !b || !c || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(to_dev(ctx, ctx->h_c, c, bytes));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(mux_dev(ctx, naive, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p, (uint32_t *)ctx->h_c.p,
+              (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+// ---- single stages --------------------------------------------------------------
+
+int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
+                                    const int32_t *bsk_index, uint32_t *trlwe_out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!trlwe_in || !bsk_index || !trlwe_out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  for (size_t i = 0; i < count; ++i)
+    if (bsk_index[i] < 0 || bsk_index[i] >= ctx->P.n) return fail(ctx, TFHE_HIP_EINVAL, "bsk_index out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)2 * kN * 4;
+  CHK(to_dev(ctx, ctx->h_a, trlwe_in, bytes));
+  CHK(to_dev(ctx, ctx->h_idx, bsk_index, count * 4));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  dim3 grid((unsigned)count), block(64);
+  const uint32_t *in = (const uint32_t *)ctx->h_a.p;
+  const int32_t *idx = (const int32_t *)ctx->h_idx.p;
+  uint32_t *o = (uint32_t *)ctx->h_out.p;
+  switch (ctx->P.l) {
+    case 1: hipLaunchKernelGGL(k_external_product<1>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
+    case 2: hipLaunchKernelGGL(k_external_product<2>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
+    default: hipLaunchKernelGGL(k_external_product<3>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return to_host(ctx, trlwe_out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count == 0) return TFHE_HIP_OK;
+  if (!trlwe || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CHK(to_dev(ctx, ctx->h_a, trlwe, count * (size_t)2 * kN * 4));
+  const size_t obytes = count * (size_t)(kN + 1) * 4;
+  CHK(ensure(ctx, ctx->h_out, obytes));
+  hipLaunchKernelGGL(k_sample_extract, dim3((unsigned)count), dim3(256), 0, ctx->stream,
+                     (const uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_out.p, count);
+  HIPCHK(ctx, hipGetLastError());
+  return to_host(ctx, out, ctx->h_out, obytes);
+}
+
+int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_lv1, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!tlwe_lv1 || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CHK(to_dev(ctx, ctx->h_a, tlwe_lv1, count * (size_t)(kN + 1) * 4));
+  const size_t obytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(ensure(ctx, ctx->h_out, obytes));
+  CHK(launch_key_switch(ctx, ctx->stream, (const uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_out.p, count));
+  return to_host(ctx, out, ctx->h_out, obytes);
+}
+
+int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count == 0) return TFHE_HIP_OK;
+  if (!res || !src) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 4));
+  CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 8));
+  hipLaunchKernelGGL(k_ifft, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+                     (const uint32_t *)ctx->h_a.p, ctx->d_tw, (double *)ctx->h_out.p);
+  HIPCHK(ctx, hipGetLastError());
+  return to_host(ctx, res, ctx->h_out, count * (size_t)kN * 8);
+}
+
+int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count == 0) return TFHE_HIP_OK;
+  if (!res || !src) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 8));
+  CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 4));
+  hipLaunchKernelGGL(k_fft, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+                     (const double *)ctx->h_a.p, ctx->d_tw, (uint32_t *)ctx->h_out.p);
+  HIPCHK(ctx, hipGetLastError());
+  return to_host(ctx, res, ctx->h_out, count * (size_t)kN * 4);
+}
+
+int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a, const uint32_t *b, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count == 0) return TFHE_HIP_OK;
+  if (!res || !a || !b) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)kN * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  hipLaunchKernelGGL(k_poly_mul, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+                     (const uint32_t *)ctx->h_a.p, (const uint32_t *)ctx->h_b.p, ctx->d_tw,
+                     (uint32_t *)ctx->h_out.p);
+  HIPCHK(ctx, hipGetLastError());
+  return to_host(ctx, res, ctx->h_out, bytes);
+}
+
+// ---- measurement ---------------------------------------------------------------
+
+int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->profiling = enabled != 0;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out) {
+  if (!ctx || !out) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  memset(out, 0, sizeof(*out));
+  auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms, uint64_t &cnt) -> int {
+    for (auto &p : v) {
+      HIPCHK(ctx, hipEventSynchronize(p.second));
+      float t = 0.f;
+      HIPCHK(ctx, hipEventElapsedTime(&t, p.first, p.second));
+      ms += (double)t;
+      ++cnt;
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    v.clear();
+    return TFHE_HIP_OK;
+  };
+  CHK(drain(ctx->ev_br, out->blind_rotate_ms, out->blind_rotate_launches));
+  CHK(drain(ctx->ev_ks, out->key_switch_ms, out->key_switch_launches));
+  out->bootstraps = ctx->bootstraps;
+  ctx->bootstraps = 0;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_synchronize(tfhe_hip_ctx *ctx) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,235 @@
+"""Engine: one C-ABI context = one GPU (one process per GPU under torch.distributed)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from .params import N, SecurityParams
+
+# gate selectors (enum tfhe_hip_gate)
+NAND, OR, AND, XOR, XNOR, NOR, ANDNY, ANDYN, ORNY, ORYN, COPY = range(11)
+GATE_IDS = {
+    "nand": NAND, "or": OR, "and": AND, "xor": XOR, "xnor": XNOR, "nor": NOR,
+    "and_ny": ANDNY, "and_yn": ANDYN, "or_ny": ORNY, "or_yn": ORYN, "copy": COPY,
+}
+
+
+def _u32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _is_tensor(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _tptr(t):
+    """Device pointer of a contiguous int32/uint32 CUDA tensor."""
+    if t is None:
+        return None
+    if not t.is_cuda or not t.is_contiguous() or t.element_size() != 4:
+        raise ValueError("device tensors must be contiguous 32-bit CUDA tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Owns a tfhe_hip_ctx.  Host arrays are numpy uint32; *_dev methods take
+    torch CUDA tensors (int32 storage of the u32 words) and only enqueue work."""
+
+    def __init__(self, params: SecurityParams, device: int = 0):
+        self.params = params
+        self.device = device
+        self._lib = _capi.lib()
+        cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
+        ctx = C.c_void_p()
+        rc = self._lib.tfhe_hip_ctx_create(C.byref(cp), device, C.byref(ctx))
+        if rc != _capi.OK:
+            msg = self._lib.tfhe_hip_last_error(None)
+            raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+        self._ctx = ctx
+        self._key_id = None
+
+    # -- lifetime -------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            self._lib.tfhe_hip_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int) -> None:
+        _capi.check(self._ctx, rc)
+
+    @property
+    def name(self) -> str:
+        return self._lib.tfhe_hip_name().decode()
+
+    # -- cloud key ------------------------------------------------------------
+    def load_cloud_key(self, cloud_key) -> None:
+        """cloud_key: any object with the reference CloudKey fields (src/key.rs:51-56):
+        decomposition_offset, blind_rotate_testvec [2][N], key_switching_key
+        [N][t][base][n+1], bootstrapping_key [n][2l][2][N] f64."""
+        p = self.params
+        bsk = np.ascontiguousarray(cloud_key.bootstrapping_key, dtype=np.float64)
+        ksk = _u32(cloud_key.key_switching_key)
+        tv = _u32(cloud_key.blind_rotate_testvec)
+        if bsk.size != p.n * 2 * p.l * 2 * N:
+            raise ValueError("bootstrapping_key has the wrong size for these parameters")
+        if ksk.size != N * p.iks_t * p.base * (p.n + 1):
+            raise ValueError("key_switching_key has the wrong size for these parameters")
+        if tv.size != 2 * N:
+            raise ValueError("blind_rotate_testvec must be [2][N]")
+        self._chk(
+            self._lib.tfhe_hip_load_cloud_key(
+                self._ctx, _ptr(bsk), _ptr(ksk), C.c_uint32(int(cloud_key.decomposition_offset)), _ptr(tv)
+            )
+        )
+        self._key_id = id(cloud_key)
+
+    def ensure_key(self, cloud_key) -> None:
+        if self._key_id != id(cloud_key):
+            self.load_cloud_key(cloud_key)
+
+    # -- batched hot path, host arrays -----------------------------------------
+    def _cts(self, a) -> np.ndarray:
+        a = _u32(a)
+        return a.reshape(-1, self.params.n + 1)
+
+    def batch_gate(self, gate: int, a, b=None) -> np.ndarray:
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if bb is not None and bb.shape != a.shape:
+            raise ValueError("operand batches differ in shape")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_gate(self._ctx, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
+        return out
+
+    def batch_bootstrap(self, cts, testvec=None, keyswitch: bool = True) -> np.ndarray:
+        cts = self._cts(cts)
+        out = np.empty_like(cts)
+        per_ct = 0
+        tv = None
+        if testvec is not None:
+            tv = _u32(testvec)
+            per_ct = int(tv.ndim == 3)
+            if per_ct and tv.shape[0] != len(cts):
+                raise ValueError("per-ciphertext test vectors: wrong count")
+        self._chk(
+            self._lib.tfhe_hip_batch_bootstrap(self._ctx, _ptr(cts), _ptr(tv), per_ct, int(keyswitch), _ptr(out), len(cts))
+        )
+        return out
+
+    def batch_blind_rotate(self, cts, testvec=None) -> np.ndarray:
+        cts = self._cts(cts)
+        out = np.empty((len(cts), 2, N), np.uint32)
+        tv = _u32(testvec) if testvec is not None else None
+        self._chk(self._lib.tfhe_hip_batch_blind_rotate(self._ctx, _ptr(cts), _ptr(tv), _ptr(out), len(cts)))
+        return out
+
+    def batch_mux(self, a, b, c, naive: bool) -> np.ndarray:
+        a, b, c = self._cts(a), self._cts(b), self._cts(c)
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_mux(self._ctx, int(naive), _ptr(a), _ptr(b), _ptr(c), _ptr(out), len(a)))
+        return out
+
+    # -- single stages ----------------------------------------------------------
+    def batch_external_product(self, trlwe, bsk_index) -> np.ndarray:
+        trlwe = _u32(trlwe).reshape(-1, 2, N)
+        idx = np.ascontiguousarray(bsk_index, dtype=np.int32).reshape(-1)
+        out = np.empty_like(trlwe)
+        self._chk(self._lib.tfhe_hip_batch_external_product(self._ctx, _ptr(trlwe), _ptr(idx), _ptr(out), len(trlwe)))
+        return out
+
+    def batch_sample_extract(self, trlwe) -> np.ndarray:
+        trlwe = _u32(trlwe).reshape(-1, 2, N)
+        out = np.empty((len(trlwe), N + 1), np.uint32)
+        self._chk(self._lib.tfhe_hip_batch_sample_extract(self._ctx, _ptr(trlwe), _ptr(out), len(trlwe)))
+        return out
+
+    def batch_identity_key_switch(self, lv1) -> np.ndarray:
+        lv1 = _u32(lv1).reshape(-1, N + 1)
+        out = np.empty((len(lv1), self.params.n + 1), np.uint32)
+        self._chk(self._lib.tfhe_hip_batch_identity_key_switch(self._ctx, _ptr(lv1), _ptr(out), len(lv1)))
+        return out
+
+    def batch_ifft(self, polys) -> np.ndarray:
+        polys = _u32(polys).reshape(-1, N)
+        out = np.empty((len(polys), N), np.float64)
+        self._chk(self._lib.tfhe_hip_batch_ifft(self._ctx, _ptr(out), _ptr(polys), len(polys)))
+        return out
+
+    def batch_fft(self, spectra) -> np.ndarray:
+        spectra = np.ascontiguousarray(spectra, dtype=np.float64).reshape(-1, N)
+        out = np.empty((len(spectra), N), np.uint32)
+        self._chk(self._lib.tfhe_hip_batch_fft(self._ctx, _ptr(out), _ptr(spectra), len(spectra)))
+        return out
+
+    def batch_poly_mul(self, a, b) -> np.ndarray:
+        a, b = _u32(a).reshape(-1, N), _u32(b).reshape(-1, N)
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_poly_mul(self._ctx, _ptr(out), _ptr(a), _ptr(b), len(a)))
+        return out
+
+    # -- device-resident path (torch CUDA tensors; enqueue only) ------------------
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            import torch
+
+            stream = torch.cuda.current_stream()
+        return C.c_void_p(stream.cuda_stream)
+
+    def batch_gate_dev(self, gate: int, a, b, out, stream=None) -> None:
+        count = a.shape[0]
+        self._chk(
+            self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream))
+        )
+
+    def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:
+        self._chk(
+            self._lib.tfhe_hip_batch_bootstrap_dev(
+                self._ctx, _tptr(cts), _tptr(testvec), int(per_ct), int(keyswitch), _tptr(out), cts.shape[0], self._stream_ptr(stream)
+            )
+        )
+
+    def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None) -> None:
+        self._chk(
+            self._lib.tfhe_hip_batch_blind_rotate_dev(
+                self._ctx, _tptr(cts), _tptr(testvec), _tptr(out_trlwe), cts.shape[0], self._stream_ptr(stream)
+            )
+        )
+
+    def batch_mux_dev(self, a, b, c, out, naive: bool, stream=None) -> None:
+        self._chk(
+            self._lib.tfhe_hip_batch_mux_dev(
+                self._ctx, int(naive), _tptr(a), _tptr(b), _tptr(c), _tptr(out), a.shape[0], self._stream_ptr(stream)
+            )
+        )
+
+    # -- measurement ------------------------------------------------------------
+    def set_profiling(self, enabled: bool) -> None:
+        self._chk(self._lib.tfhe_hip_set_profiling(self._ctx, int(enabled)))
+
+    def kernel_times(self) -> dict:
+        kt = _capi.KernelTimes()
+        self._chk(self._lib.tfhe_hip_get_kernel_times(self._ctx, C.byref(kt)))
+        return {
+            "blind_rotate_ms": kt.blind_rotate_ms,
+            "key_switch_ms": kt.key_switch_ms,
+            "blind_rotate_launches": int(kt.blind_rotate_launches),
+            "key_switch_launches": int(kt.key_switch_launches),
+            "bootstraps": int(kt.bootstraps),
+        }
+
+    def synchronize(self) -> None:
+        self._chk(self._lib.tfhe_hip_synchronize(self._ctx))

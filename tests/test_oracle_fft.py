@@ -1,0 +1,115 @@
+"""Oracle FFT layer vs the reference's own FFT test inputs and tolerances
+(src/fft/mod.rs:119-238, src/fft/klemsa.rs:183-202, src/fft/processors.rs:783-855),
+vs the DFT definition, and vs the reference's SPQLIOS C++/asm build (oracle/_ref)."""
+import numpy as np
+import pytest
+
+from conftest import signed_diff
+
+N = 1024
+
+
+def test_dft_definition(O):
+    """orc_cfft512 computes the un-normalised DFT rustfft computes (klemsa.rs:62-65)."""
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(512) + 1j * rng.standard_normal(512)
+    assert np.abs(O.cfft512(x) - np.fft.fft(x)).max() < 1e-11
+    assert np.abs(O.cfft512(x, inverse=True) - np.fft.ifft(x) * 512).max() < 1e-11
+
+
+def test_klemsa_spectrum_layout(O):
+    """bin k = evaluation at exp(i*pi*(1-4k)/N) * 2, stored re[0..512] || im[0..512]."""
+    rng = np.random.default_rng(2)
+    p = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+    spec = O.klemsa_ifft(p)
+    x = p.view(np.int32).astype(np.float64)
+    z = (x[:512] + 1j * x[512:]) * np.exp(1j * np.pi * np.arange(512) / N)
+    ref = 2.0 * np.fft.fft(z)
+    scale = np.abs(ref).max()
+    assert np.abs(spec[:512] - ref.real).max() < 1e-12 * scale
+    assert np.abs(spec[512:] - ref.imag).max() < 1e-12 * scale
+
+
+def test_kat_klemsa_roundtrip(O, golden):
+    """klemsa.rs:183-202: in[0]=2^31, in[5]=2^30, |out-in| < 2."""
+    x = golden["stage"]["kat_klemsa_roundtrip"]
+    assert signed_diff(O.klemsa_fft(O.klemsa_ifft(x)), x) < 2
+
+
+def test_kat_delta(O, golden):
+    """fft/mod.rs:162-177: delta 1000, |diff| < 10."""
+    x = golden["stage"]["kat_delta"]
+    assert signed_diff(O.klemsa_fft(O.klemsa_ifft(x)), x) < 10
+
+
+def test_random_roundtrip(O):
+    """fft/mod.rs:119-133, 180-210: random torus, |diff| < 2."""
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        a = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+        assert signed_diff(O.klemsa_fft(O.klemsa_ifft(a)), a) < 2
+
+
+@pytest.mark.parametrize("pair", ["consistency", "dense"])
+def test_kat_poly_mul_vs_schoolbook(O, golden, pair):
+    """processors.rs:809-813, 850-855 deterministic inputs (< 2^20 each: sums < 2^50, exact
+    in f64), expected = exact schoolbook, |diff| < 2."""
+    g = golden["stage"]
+    a, b = g[f"kat_{pair}_a"], g[f"kat_{pair}_b"]
+    exp = g[f"kat_{pair}_expected"]
+    assert np.array_equal(O.negacyclic_schoolbook(a, b), exp)
+    assert signed_diff(O.klemsa_poly_mul(a, b), exp) < 2
+
+
+def test_kat_sparse_is_integer_only(O, golden):
+    """processors.rs:783-786 (orphan, never compiled): a=2^28, b=2^27 every 20th slot.
+    Every product is 2^55 = 0 mod 2^32 and the sums reach 2^60 > 2^53, so no f64 FFT can
+    be held to +-1 here; the vector pins the exact schoolbook only (expected: all zero)."""
+    g = golden["stage"]
+    exp = O.negacyclic_schoolbook(g["kat_sparse_a"], g["kat_sparse_b"])
+    assert np.array_equal(exp, g["kat_sparse_expected"]) and not exp.any()
+
+
+def test_random_poly_mul_vs_schoolbook(O):
+    """fft/mod.rs:136-159, 213-238: a uniform, b < Bg; tolerance < 2 (measured 0)."""
+    rng = np.random.default_rng(4)
+    worst = 0
+    for _ in range(30):
+        a = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 64, N, dtype=np.uint64).astype(np.uint32)
+        worst = max(worst, signed_diff(O.klemsa_poly_mul(a, b), O.negacyclic_schoolbook(a, b)))
+    assert worst < 2
+
+
+def test_schoolbook_independent(O):
+    """the oracle's schoolbook equals an independent numpy big-int negacyclic product mod 2^32."""
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+    full = np.zeros(2 * N, dtype=object)
+    A = a.astype(object)
+    for i in range(N):
+        full[i:i + N] += A * int(b[i])
+    ref = np.array([(int(full[i]) - int(full[i + N])) % (1 << 32) for i in range(N)], dtype=np.uint64).astype(np.uint32)
+    assert np.array_equal(O.negacyclic_schoolbook(a, b), ref)
+
+
+def test_reference_spqlios_cross_check(O, golden):
+    """The reference's own SPQLIOS negacyclic FFT (compiled from /root/reference into
+    oracle/_ref) agrees with the oracle's products within its truncation (+-1 LSB)."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    rng = np.random.default_rng(6)
+    g = golden["stage"]
+    cases = [(g[f"kat_{p}_a"], g[f"kat_{p}_b"]) for p in ("consistency", "dense")]
+    for _ in range(10):
+        cases.append(
+            (rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32),
+             rng.integers(0, 64, N, dtype=np.uint64).astype(np.uint32))
+        )
+    for a, b in cases:
+        ref = O.ref_poly_mul(a, b)
+        assert signed_diff(ref, O.negacyclic_schoolbook(a, b)) <= 1
+        assert signed_diff(ref, O.klemsa_poly_mul(a, b)) <= 1
+    x = g["kat_klemsa_roundtrip"]
+    assert signed_diff(O.ref_roundtrip(x), x) <= 1
