@@ -80,6 +80,13 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `make -C rs-tfhe_amd/csrc` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback."
             )
+        # In a PyTorch process the HIP runtime torch bundles must be the one (and only) runtime
+        # in the address space: load torch first so libtfhe_hip.so binds to it by SONAME.  (Two
+        # HIP/HSA runtimes in one process leave the second without a device.)
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported

@@ -174,8 +174,12 @@ def test_reference_api_mirror(O, keys128):
     assert bs.name() == "hip-gfx950"
     assert sk.decrypt_bool(bs.bootstrap(ct_t, pk))[0] and not sk.decrypt_bool(bs.bootstrap(ct_f, pk))[0]
     assert np.array_equal(bs.bootstrap_without_key_switch(ct_t, pk), O.batch_bootstrap(ck, ct_t, keyswitch=False)[0])
-    g = R.Gates.with_bootstrap(R.LutBootstrap())  # non-fused strategy: host prep + LUT bootstrap
-    assert not sk.decrypt_bool(g.and_(ct_t, ct_f, pk))[0] and sk.decrypt_bool(g.or_(ct_t, ct_f, pk))[0]
+    # non-fused strategy (Gates::with_bootstrap, gates.rs:43-45): host prep, then the strategy's
+    # bootstrap() -- for LutBootstrap that is the m=2 identity LUT (lut.rs:108-111)
+    g = R.Gates.with_bootstrap(R.LutBootstrap())
+    assert g.bootstrap_strategy() == "lut-hip-gfx950"
+    want = O.batch_bootstrap(ck, O.gate_prep(O.GATE_AND, ct_t, ct_f, 700), testvec=O.lut_generate(lambda x: x, 2))[0]
+    assert np.array_equal(g.and_(ct_t, ct_f, pk), want)
 
 
 def test_mux_variants(O, eng128, keys128):
