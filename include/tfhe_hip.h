@@ -56,7 +56,7 @@ extern "C" {
 
 /* Run-time form of SecurityParams / TrgswParams (src/params.rs:53-84). */
 typedef struct tfhe_hip_params {
-  int32_t n;       /* tlwe_lv0.n   (<= 2047)            */
+  int32_t n;       /* tlwe_lv0.n   (<= 1279)            */
   int32_t l;       /* trgsw_lv1.l  (1..3)               */
   int32_t bgbit;   /* trgsw_lv1.bgbit (l*bgbit <= 32)   */
   int32_t basebit; /* trgsw_lv1.basebit                 */

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtfhe_hip.so")
+LIB_PATH = os.environ.get("TFHE_HIP_LIB", os.path.join(_HERE, "libtfhe_hip.so"))  # env: kernel A/B experiments only
 
 OK, EINVAL, EHIP, ENOKEY, ENOMEM = 0, -1, -2, -3, -4
 

@@ -1,11 +1,12 @@
 // blind_rotate.hpp -- the persistent blind-rotation kernel and its stage kernels.
 //
 // Mapping: one 64-lane wavefront (= one workgroup) owns one ciphertext for all
-// n CMUX steps.  The TRLWE accumulator never leaves the wave: lane l keeps
-// coefficients {l+64m, l+64m+512 : m<8} of both polynomials in 32 VGPRs, the
-// same distribution the folded FFT consumes and produces, so there is no
-// repacking between steps.  LDS per wave: one 9216-byte FFT tile (also used to
-// realise the X^k rotation as an indexed re-read) + the n rotation amounts.
+// n CMUX steps.  The TRLWE accumulator never leaves the CU: it sits in a
+// wave-private 8 KiB LDS array in natural coefficient order; lane l works on
+// coefficients {l+64m, l+64m+512 : m<8}, the distribution the folded FFT
+// consumes and produces, so there is no repacking between steps and X^k * acc
+// is an indexed re-read.  LDS per wave: 9216-byte FFT tile + 8192-byte
+// accumulator + the n rotation amounts (~18.8 KiB -> 8 waves per CU).
 //
 // Reference semantics reproduced here (paths relative to the rs-tfhe repo):
 //   blind_rotate / blind_rotate_with_testvec   src/trgsw.rs:198-226, 242-274
@@ -24,9 +25,6 @@ namespace tfhe {
 // Bootstrapping key in engine order: [n][2l][2][8][64] complex (double2),
 // element (i, r, c, s, mu) = reference bin bin_of(mu, s) of
 // bootstrapping_key[i].trlwe_fft[r].{a,b}, times 2^-10 (exact).
-__device__ __forceinline__ size_t bsk_offset(int i, int r, int c, int two_l) {
-  return ((size_t)(i * two_l + r) * 2 + c) * kN2;
-}
 
 // X^k * p evaluated at coefficient j (k in [0, 2N]), reading p from LDS/global:
 // idx = (j - k) mod 2N; idx < N ? p[idx] : MAX - p[idx-N]   (trgsw.rs:315-327)
@@ -37,87 +35,79 @@ __device__ __forceinline__ uint32_t rot_read(const P *p, int j, int k) {
   return (idx & kN) ? ~v : v;  // Torus::MAX - v == ~v
 }
 
-struct Acc {
-  uint32_t a_lo[8], a_hi[8], b_lo[8], b_hi[8];  // coefficient l+64m / l+64m+512
-};
+using f64x2 = __attribute__((ext_vector_type(2))) double;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-// One external product accumulated into acc:  acc += BSK[i] (x) (X^k*acc - acc)
-// (cmux with in1 = acc, in2 = X^k * acc).  `tile` is the wave's LDS tile.
+__device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, uint32_t soff) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)soff, 0);
+  return __builtin_bit_cast(f64x2, v);
+}
+
+// ---- the external-product core shared by every kernel --------------------------
+// One half of an external product: the L decomposition digits of ONE polynomial of
+// the TRLWE (half_sel 0: a -> key rows 0..L-1, 1: b -> rows L..2L-1), each digit
+// polynomial through a forward FFT and multiply-accumulated against its key row.
+// In:  t_lo/hi[m] = (coefficient + decomposition offset), folded-FFT distribution
+//      (lane l: coefficients l+64m and l+64m+512).
+// Acc: fa / fb = the two accumulated spectra (un-normalised; the key carries 2^-10)
+//      in the forward-FFT bin order, ready for fft_inverse.
+//      (decomposition trgsw.rs:144-171, batch_ifft + fma_in_fd_1024 trgsw.rs:99-106)
+// How many of the 8 b-half key loads of a row are issued before the forward FFT (the 8
+// a-half loads always are).  8 = whole row in flight across the FFT (64 VGPRs).
+#ifndef TFHE_PREFETCH_A
+#define TFHE_PREFETCH_A 8
+#endif
+#ifndef TFHE_PREFETCH_B
+#define TFHE_PREFETCH_B 0
+#endif
+constexpr int kPrefetchA = TFHE_PREFETCH_A;
+constexpr int kPrefetchB = TFHE_PREFETCH_B;
+
 template <int L>
-__device__ __forceinline__ void cmux_step(Acc &acc, int k, const double2 *__restrict__ bsk_i,
-                                          const Twiddles &tw, double2 *tile, int lane, int bgbit,
-                                          uint32_t offset) {
-  uint32_t *tile32 = reinterpret_cast<uint32_t *>(tile);
-  // ---- tmp = X^k * acc - acc  (rotation through LDS) -----------------------
-  wave_lds_sync();
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    tile32[lane + 64 * m] = acc.a_lo[m];
-    tile32[lane + 64 * m + kN2] = acc.a_hi[m];
-    tile32[kN + lane + 64 * m] = acc.b_lo[m];
-    tile32[kN + lane + 64 * m + kN2] = acc.b_hi[m];
-  }
-  wave_lds_sync();
-  uint32_t ta_lo[8], ta_hi[8], tb_lo[8], tb_hi[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    int j = lane + 64 * m;
-    ta_lo[m] = rot_read(tile32, j, k) - acc.a_lo[m] + offset;
-    ta_hi[m] = rot_read(tile32, j + kN2, k) - acc.a_hi[m] + offset;
-    tb_lo[m] = rot_read(tile32 + kN, j, k) - acc.b_lo[m] + offset;
-    tb_hi[m] = rot_read(tile32 + kN, j + kN2, k) - acc.b_hi[m] + offset;
-  }
-  // ---- 2l forward FFTs + pointwise MAC against the key row -----------------
-  double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
+__device__ __forceinline__ void external_product_half(int half_sel, const uint32_t (&t_lo)[8],
+                                                      const uint32_t (&t_hi)[8],
+                                                      __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
+                                                      const Twiddles &tw, double2 *tile, int lane, int bgbit,
+                                                      double (&fa_re)[8], double (&fa_im)[8],
+                                                      double (&fb_re)[8], double (&fb_im)[8]) {
+  const uint32_t lane_off = (uint32_t)lane * 16u;
   const uint32_t mask = (1u << bgbit) - 1u;
   const int32_t half = 1 << (bgbit - 1);
-#pragma unroll
-  for (int half_sel = 0; half_sel < 2; ++half_sel) {  // 0: digits of a, 1: digits of b
 #pragma unroll 1
-    for (int i = 0; i < L; ++i) {
-      const int r = half_sel * L + i;
-      const int shift = 32 - (i + 1) * bgbit;
-      double re[8], im[8];
+  for (int i = 0; i < L; ++i) {
+    const int r = half_sel * L + i;
+    const int shift = 32 - (i + 1) * bgbit;
+    // key row r: 2 x 8 coalesced 16-byte loads per lane off one buffer descriptor (lane
+    // offset in a VGPR, row offset in an SGPR: no per-lane address arithmetic), issued
+    // ahead of the FFT they are consumed after, so their latency hides under it.
+    const uint32_t row_off = bsk_i_off + (uint32_t)r * (2u * kN2 * 16u);
+    f64x2 va[8], vb[8];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        uint32_t lo = half_sel ? tb_lo[m] : ta_lo[m];
-        uint32_t hi = half_sel ? tb_hi[m] : ta_hi[m];
-        re[m] = (double)((int32_t)((lo >> shift) & mask) - half);
-        im[m] = (double)((int32_t)((hi >> shift) & mask) - half);
-      }
-      // key row: issue the loads before the FFT so they overlap it
-      const double2 *ka = bsk_i + ((size_t)r * 2 + 0) * kN2 + lane;
-      const double2 *kb = bsk_i + ((size_t)r * 2 + 1) * kN2 + lane;
-      double2 va[8], vb[8];
+    for (int s = 0; s < kPrefetchA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        va[s] = ka[s * 64];
-        vb[s] = kb[s * 64];
-      }
-      fft_forward(re, im, tw, tile, lane);
+    for (int s = 0; s < kPrefetchB; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
+    double re[8], im[8];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        fa_re[s] += re[s] * va[s].x - im[s] * va[s].y;
-        fa_im[s] += re[s] * va[s].y + im[s] * va[s].x;
-        fb_re[s] += re[s] * vb[s].x - im[s] * vb[s].y;
-        fb_im[s] += re[s] * vb[s].y + im[s] * vb[s].x;
-      }
+    for (int m = 0; m < 8; ++m) {
+      re[m] = (double)((int32_t)((t_lo[m] >> shift) & mask) - half);
+      im[m] = (double)((int32_t)((t_hi[m] >> shift) & mask) - half);
     }
-  }
-  // ---- 2 inverse FFTs, round, accumulate -----------------------------------
-  fft_inverse(fa_re, fa_im, tw, tile, lane);
+    fft_forward(re, im, tw, tile, lane);
+    // the rest of the row is fetched behind the first MACs
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    acc.a_lo[m] += round_to_torus(fa_re[m]);
-    acc.a_hi[m] += round_to_torus(fa_im[m]);
-  }
-  fft_inverse(fb_re, fb_im, tw, tile, lane);
+    for (int s = kPrefetchA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    acc.b_lo[m] += round_to_torus(fb_re[m]);
-    acc.b_hi[m] += round_to_torus(fb_im[m]);
+    for (int s = kPrefetchB; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      fa_re[s] += re[s] * va[s].x - im[s] * va[s].y;
+      fa_im[s] += re[s] * va[s].y + im[s] * va[s].x;
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      fb_re[s] += re[s] * vb[s].x - im[s] * vb[s].y;
+      fb_im[s] += re[s] * vb[s].y + im[s] * vb[s].x;
+    }
   }
 }
 
@@ -138,17 +128,30 @@ struct BlindRotateArgs {
   uint32_t *out_ext2;   // [count][n+1]  sample_extract_index_2(.,0)
 };
 
-template <int L>
-__global__ __launch_bounds__(64) void k_blind_rotate(BlindRotateArgs A) {
+// LDS per workgroup: FFT tile | accumulator (a then b, natural order) | T2 table | rotation amounts
+constexpr int kAccBytes = 2 * kN * 4;
+__host__ __device__ __forceinline__ size_t blind_rotate_lds_bytes(int n) {
+  return ((size_t)kTileBytes + kAccBytes + kT2Bytes + (size_t)n * 2 + 15) & ~(size_t)15;
+}
+constexpr int kStageLdsBytes = kTileBytes + kT2Bytes;  // stage kernels: tile | T2 table
+
+// The TRLWE accumulator lives in a wave-private LDS array for the whole n-step
+// chain.  X^k * acc is then just an indexed re-read of that array (poly_mul_with_x_k
+// never materialises), and the 32 VGPRs an in-register accumulator would pin across
+// the eight FFTs are free, which is what lets two waves share a SIMD (<= 256 VGPRs).
+template <int L, bool FAST, int WPS>
+__global__ __launch_bounds__(64, WPS) void k_blind_rotate(BlindRotateArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
-  uint16_t *s_abar = reinterpret_cast<uint16_t *>(smem + kTileBytes);
+  uint32_t *acc = reinterpret_cast<uint32_t *>(smem + kTileBytes);
+  double2 *t2tab = reinterpret_cast<double2 *>(smem + kTileBytes + kAccBytes);
+  uint16_t *s_abar = reinterpret_cast<uint16_t *>(smem + kTileBytes + kAccBytes + kT2Bytes);
   const int lane = threadIdx.x;
   const size_t ct = blockIdx.x;
   const int n = A.n;
 
   Twiddles tw;
-  tw.load(A.tw, lane);
+  tw.load(A.tw, t2tab, lane);
 
   // ---- gate linear prep + rotation amounts ---------------------------------
   const uint32_t *pa = A.in_a + ct * (size_t)(n + 1);
@@ -167,141 +170,126 @@ __global__ __launch_bounds__(64) void k_blind_rotate(BlindRotateArgs A) {
 
   // ---- acc = X^b_tilda * testvec -------------------------------------------
   const uint32_t *tv = A.testvec + ct * A.per_ct_stride;
-  Acc acc;
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < 16; ++m) {
     int j = lane + 64 * m;
-    acc.a_lo[m] = rot_read(tv, j, b_tilda);
-    acc.a_hi[m] = rot_read(tv, j + kN2, b_tilda);
-    acc.b_lo[m] = rot_read(tv + kN, j, b_tilda);
-    acc.b_hi[m] = rot_read(tv + kN, j + kN2, b_tilda);
+    acc[j] = rot_read(tv, j, b_tilda);
+    acc[kN + j] = rot_read(tv + kN, j, b_tilda);
   }
   __syncthreads();
 
-  // ---- n sequential CMUXes --------------------------------------------------
-  const size_t per_i = (size_t)2 * L * 2 * kN2;
+  // ---- n sequential CMUXes: acc += BSK[i] (x) (X^a_tilda * acc - acc) ------
+  constexpr uint32_t per_i_bytes = 2u * L * 2u * kN2 * 16u;  // one TRGSW in engine order
+  const __amdgpu_buffer_rsrc_t bsk_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)A.bsk, 0, (int)((uint32_t)n * per_i_bytes), 0x00020000);
+  const uint32_t offset = A.offset;
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int k = s_abar[i];
-    cmux_step<L>(acc, k, A.bsk + (size_t)i * per_i, tw, tile, lane, A.bgbit, A.offset);
+    double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
+    // cmux: tmp = in2 - in1 = X^k*acc - acc (trgsw.rs:183-186), + decomposition offset; the a
+    // half is consumed before the b half is formed, so only 16 of these are ever live
+#pragma unroll
+    for (int half_sel = 0; half_sel < 2; ++half_sel) {
+      const uint32_t *p = acc + half_sel * kN;
+      uint32_t t_lo[8], t_hi[8];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int j = lane + 64 * m;
+        t_lo[m] = rot_read(p, j, k) - p[j] + offset;
+        t_hi[m] = rot_read(p, j + kN2, k) - p[j + kN2] + offset;
+      }
+      external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane,
+                               A.bgbit, fa_re, fa_im, fb_re, fb_im);
+    }
+    fft_inverse(fa_re, fa_im, tw, tile, lane);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
+      const int j = lane + 64 * m;
+      acc[j] += round_to_torus<FAST>(fa_re[m]);
+      acc[j + kN2] += round_to_torus<FAST>(fa_im[m]);
+    }
+    fft_inverse(fb_re, fb_im, tw, tile, lane);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int j = lane + 64 * m;
+      acc[kN + j] += round_to_torus<FAST>(fb_re[m]);
+      acc[kN + j + kN2] += round_to_torus<FAST>(fb_im[m]);
+    }
+    wave_lds_sync();  // the next step re-reads acc at rotated (other lanes') positions
   }
 
-  // ---- epilogue --------------------------------------------------------------
+  // ---- epilogue (acc is final; any lane may read any coefficient) -------------
   if (A.out_trlwe) {
     uint32_t *o = A.out_trlwe + ct * (size_t)(2 * kN);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int j = lane + 64 * m;
-      o[j] = acc.a_lo[m];
-      o[j + kN2] = acc.a_hi[m];
-      o[kN + j] = acc.b_lo[m];
-      o[kN + j + kN2] = acc.b_hi[m];
-    }
+    for (int m = 0; m < 32; ++m) o[lane + 64 * m] = acc[lane + 64 * m];
   }
   if (A.out_lv1) {
     // p[0]=a[0]; p[i]=MAX-a[N-i]; p[N]=b[0]   (trlwe.rs:106-120 with k=0)
     uint32_t *o = A.out_lv1 + ct * (size_t)(kN + 1);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int j = lane + 64 * m;
-      if (j == 0) {
-        o[0] = acc.a_lo[m];
-        o[kN] = acc.b_lo[m];
-      } else {
-        o[kN - j] = ~acc.a_lo[m];
-      }
-      o[kN - (j + kN2)] = ~acc.a_hi[m];
+    for (int m = 0; m < 16; ++m) {
+      const int i = lane + 64 * m;
+      o[i] = i == 0 ? acc[0] : ~acc[kN - i];
     }
+    if (lane == 0) o[kN] = acc[kN];
   }
   if (A.out_ext2) {
     // same formula with N := n   (trlwe.rs:122-136 with k=0)
     uint32_t *o = A.out_ext2 + ct * (size_t)(n + 1);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      int j = lane + 64 * m;
-      if (j == 0) {
-        o[0] = acc.a_lo[m];
-        o[n] = acc.b_lo[m];
-      } else if (j < n) {
-        o[n - j] = ~acc.a_lo[m];
-      }
-      int jh = j + kN2;
-      if (jh < n) o[n - jh] = ~acc.a_hi[m];
-    }
+    for (int i = lane; i < n; i += 64) o[i] = i == 0 ? acc[0] : ~acc[n - i];
+    if (lane == 0) o[n] = acc[kN];
   }
 }
 
 // ---- stage kernels (parity tests; same device code) --------------------------
 
 // external_product_with_fft (trgsw.rs:77-116): out = BSK[idx] (x) in
-template <int L>
+template <int L, bool FAST>
 __global__ __launch_bounds__(64) void k_external_product(const uint32_t *in, const int32_t *bsk_index,
-                                                          const double2 *bsk, const double2 *twt,
-                                                          int bgbit, uint32_t offset, uint32_t *out) {
+                                                          const double2 *bsk, uint32_t bsk_bytes,
+                                                          const double2 *twt, int bgbit, uint32_t offset,
+                                                          uint32_t *out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
   const int lane = threadIdx.x;
   const size_t ct = blockIdx.x;
   Twiddles tw;
-  tw.load(twt, lane);
-  // cmux_step computes acc += BSK (x) (X^k acc - acc).  With k = N the rotated
-  // value is MAX - acc = -acc - 1, so feed it directly instead: use the
-  // decomposition input t = in (not a difference) by building the step by hand.
-  const uint32_t *p = in + ct * (size_t)(2 * kN);
-  uint32_t ta_lo[8], ta_hi[8], tb_lo[8], tb_hi[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    int j = lane + 64 * m;
-    ta_lo[m] = p[j] + offset;
-    ta_hi[m] = p[j + kN2] + offset;
-    tb_lo[m] = p[kN + j] + offset;
-    tb_hi[m] = p[kN + j + kN2] + offset;
-  }
-  const double2 *bsk_i = bsk + (size_t)bsk_index[ct] * ((size_t)2 * L * 2 * kN2);
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
+  constexpr uint32_t per_i_bytes = 2u * L * 2u * kN2 * 16u;
+  const __amdgpu_buffer_rsrc_t bsk_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)bsk, 0, (int)bsk_bytes, 0x00020000);
+  const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane(bsk_index[ct]);
   double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
-  const uint32_t mask = (1u << bgbit) - 1u;
-  const int32_t half = 1 << (bgbit - 1);
 #pragma unroll
   for (int half_sel = 0; half_sel < 2; ++half_sel) {
-#pragma unroll 1
-    for (int i = 0; i < L; ++i) {
-      const int r = half_sel * L + i;
-      const int shift = 32 - (i + 1) * bgbit;
-      double re[8], im[8];
+    const uint32_t *p = in + ct * (size_t)(2 * kN) + half_sel * kN;
+    uint32_t t_lo[8], t_hi[8];
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        uint32_t lo = half_sel ? tb_lo[m] : ta_lo[m];
-        uint32_t hi = half_sel ? tb_hi[m] : ta_hi[m];
-        re[m] = (double)((int32_t)((lo >> shift) & mask) - half);
-        im[m] = (double)((int32_t)((hi >> shift) & mask) - half);
-      }
-      const double2 *ka = bsk_i + ((size_t)r * 2 + 0) * kN2 + lane;
-      const double2 *kb = bsk_i + ((size_t)r * 2 + 1) * kN2 + lane;
-      fft_forward(re, im, tw, tile, lane);
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        double2 va = ka[s * 64], vb = kb[s * 64];
-        fa_re[s] += re[s] * va.x - im[s] * va.y;
-        fa_im[s] += re[s] * va.y + im[s] * va.x;
-        fb_re[s] += re[s] * vb.x - im[s] * vb.y;
-        fb_im[s] += re[s] * vb.y + im[s] * vb.x;
-      }
+    for (int m = 0; m < 8; ++m) {
+      t_lo[m] = p[lane + 64 * m] + offset;
+      t_hi[m] = p[lane + 64 * m + kN2] + offset;
     }
+    external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, fa_re, fa_im,
+                             fb_re, fb_im);
   }
   uint32_t *o = out + ct * (size_t)(2 * kN);
   fft_inverse(fa_re, fa_im, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    o[lane + 64 * m] = round_to_torus(fa_re[m]);
-    o[lane + 64 * m + kN2] = round_to_torus(fa_im[m]);
+    o[lane + 64 * m] = round_to_torus<FAST>(fa_re[m]);
+    o[lane + 64 * m + kN2] = round_to_torus<FAST>(fa_im[m]);
   }
   fft_inverse(fb_re, fb_im, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    o[kN + lane + 64 * m] = round_to_torus(fb_re[m]);
-    o[kN + lane + 64 * m + kN2] = round_to_torus(fb_im[m]);
+    o[kN + lane + 64 * m] = round_to_torus<FAST>(fb_re[m]);
+    o[kN + lane + 64 * m + kN2] = round_to_torus<FAST>(fb_im[m]);
   }
 }
 
@@ -312,7 +300,7 @@ __global__ __launch_bounds__(64) void k_ifft(const uint32_t *src, const double2 
   const int lane = threadIdx.x;
   const size_t p = blockIdx.x;
   Twiddles tw;
-  tw.load(twt, lane);
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
   double re[8], im[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -335,7 +323,7 @@ __global__ __launch_bounds__(64) void k_fft(const double *src, const double2 *tw
   const int lane = threadIdx.x;
   const size_t p = blockIdx.x;
   Twiddles tw;
-  tw.load(twt, lane);
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
   double re[8], im[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -359,7 +347,7 @@ __global__ __launch_bounds__(64) void k_poly_mul(const uint32_t *a, const uint32
   const int lane = threadIdx.x;
   const size_t p = blockIdx.x;
   Twiddles tw;
-  tw.load(twt, lane);
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
   double are[8], aim[8], bre[8], bim[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) {

@@ -57,19 +57,24 @@ __device__ constexpr double kCmIm[8] = {0.0,
 // Per-lane twiddles, loaded once per kernel from the context's table
 // (computed on the host in long double): tw[0..511] = T1[k1][lane] as
 // [k1*64+lane], tw[512..575] = T2[k2][l1] as [512 + k2*8 + l1].
+//
+// T1 (lane-dependent, 8 complex) stays in registers for the whole kernel; T2 has only
+// 64 distinct values, so it sits in a 1 KiB LDS table read as it is used -- that frees
+// 28 VGPRs, which is what lets the key-row prefetch fit beside two waves per SIMD.
+constexpr int kT2Bytes = 64 * 16;
 struct Twiddles {
   double t1re[8], t1im[8];
-  double t2re[8], t2im[8];
-  __device__ __forceinline__ void load(const double2 *__restrict__ tw, int lane) {
+  const double2 *t2;  // LDS: [k2*8 + l1]
+  __device__ __forceinline__ void load(const double2 *__restrict__ tw, double2 *t2_lds, int lane) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       double2 a = tw[k * 64 + lane];
       t1re[k] = a.x;
       t1im[k] = a.y;
-      double2 b = tw[512 + k * 8 + (lane & 7)];
-      t2re[k] = b.x;
-      t2im[k] = b.y;
     }
+    t2_lds[lane] = tw[512 + lane];
+    t2 = t2_lds;
+    __syncthreads();
   }
 };
 
@@ -168,7 +173,10 @@ __device__ __forceinline__ void fft_forward(double (&re)[8], double (&im)[8], co
   }
   dft8<false>(re, im);
 #pragma unroll
-  for (int k = 1; k < 8; ++k) cmul<false>(re[k], im[k], tw.t2re[k], tw.t2im[k]);
+  for (int k = 1; k < 8; ++k) {
+    const double2 w = tw.t2[k * 8 + lo];
+    cmul<false>(re[k], im[k], w.x, w.y);
+  }
   // transpose B: write (k1, k2, l1) at k1*72 + k2*9 + l1 ; read lane (k1, k2') slot l1
   wave_lds_sync();
 #pragma unroll
@@ -202,7 +210,10 @@ __device__ __forceinline__ void fft_inverse(double (&re)[8], double (&im)[8], co
     im[k] = v.y;
   }
 #pragma unroll
-  for (int k = 1; k < 8; ++k) cmul<true>(re[k], im[k], tw.t2re[k], tw.t2im[k]);
+  for (int k = 1; k < 8; ++k) {
+    const double2 w = tw.t2[k * 8 + lo];
+    cmul<true>(re[k], im[k], w.x, w.y);
+  }
   dft8<true>(re, im);  // over k2 -> l2
   wave_lds_sync();
 #pragma unroll
@@ -223,11 +234,22 @@ __device__ __forceinline__ void fft_inverse(double (&re)[8], double (&im)[8], co
 
 // f64::round (half away from zero) then `as i64 as u32` (klemsa.rs:145-146):
 // low 32 bits of the rounded integer, exact for |x| < 2^63.
+//
+// FAST: valid when |x| < 2^51 is guaranteed (the host checks
+// 2l * N * (Bg/2) * 2^31 < 2^51, true for l=3,bgbit=6): adding 1.5*2^52 leaves
+// round-to-nearest(x) in the low mantissa bits and 1.5*2^52 = 0 mod 2^32.  It
+// differs from f64::round only on exact .5 ties, which cannot occur where the
+// FFT product is exact (|x - integer| <= 0.004).
+template <bool FAST = false>
 __device__ __forceinline__ uint32_t round_to_torus(double x) {
-  double r = round(x);
-  double hi = floor(r * 0x1p-32);
-  double lo = fma(hi, -0x1p32, r);
-  return (uint32_t)lo;
+  if (FAST) {
+    return (uint32_t)__double2loint(x + 0x1.8p52);
+  } else {
+    double r = round(x);
+    double hi = floor(r * 0x1p-32);
+    double lo = fma(hi, -0x1p32, r);
+    return (uint32_t)lo;
+  }
 }
 
 // bin held by (lane mu, slot s) after fft_forward

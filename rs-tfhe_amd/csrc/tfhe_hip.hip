@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -25,7 +26,7 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
-constexpr int kKsG = 8;  // ciphertexts per key-switch workgroup
+constexpr int kKsG = 32;  // ciphertexts per key-switch workgroup
 
 struct DevBuf {
   void *p = nullptr;
@@ -48,6 +49,11 @@ struct tfhe_hip_ctx {
   std::mutex mu;
   std::string err = "";
   bool profiling = false;
+  int num_cus = 0;
+  bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
+  int br_wps = 2;  // blind-rotate waves per SIMD the kernel is compiled for (register budget 512 / wps)
+  size_t br_lds_pad = 0;  // experiment knob: extra LDS per workgroup to lower residency
+  long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
 };
@@ -129,10 +135,31 @@ int record_end(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_
   return TFHE_HIP_OK;
 }
 
-size_t br_lds_bytes(const tfhe_hip_ctx *ctx) {
-  size_t b = kTileBytes + (size_t)ctx->P.n * 2;
-  return (b + 15) & ~(size_t)15;
+typedef void (*br_kernel_t)(BlindRotateArgs);
+br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
+  const bool f = ctx->fast_round;
+  switch (ctx->P.l) {
+    case 1: return ctx->br_wps == 2 ? (f ? k_blind_rotate<1, true, 2> : k_blind_rotate<1, false, 2>)
+                                    : (f ? k_blind_rotate<1, true, 1> : k_blind_rotate<1, false, 1>);
+    case 2: return ctx->br_wps == 2 ? (f ? k_blind_rotate<2, true, 2> : k_blind_rotate<2, false, 2>)
+                                    : (f ? k_blind_rotate<2, true, 1> : k_blind_rotate<2, false, 1>);
+    default: return ctx->br_wps == 2 ? (f ? k_blind_rotate<3, true, 2> : k_blind_rotate<3, false, 2>)
+                                     : (f ? k_blind_rotate<3, true, 1> : k_blind_rotate<3, false, 1>);
+  }
 }
+
+typedef void (*ep_kernel_t)(const uint32_t *, const int32_t *, const double2 *, uint32_t, const double2 *, int,
+                            uint32_t, uint32_t *);
+ep_kernel_t ep_kernel(const tfhe_hip_ctx *ctx) {
+  const bool f = ctx->fast_round;
+  switch (ctx->P.l) {
+    case 1: return f ? k_external_product<1, true> : k_external_product<1, false>;
+    case 2: return f ? k_external_product<2, true> : k_external_product<2, false>;
+    default: return f ? k_external_product<3, true> : k_external_product<3, false>;
+  }
+}
+
+size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx->P.n) + ctx->br_lds_pad; }
 
 int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, const uint32_t *in_b,
                         GatePrep gp, const uint32_t *testvec, int per_ct, size_t count,
@@ -156,17 +183,37 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.out_lv1 = out_lv1;
   A.out_ext2 = out_ext2;
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
-  dim3 grid((unsigned)count), block(64);
+  dim3 block(64);
   size_t lds = br_lds_bytes(ctx);
-  CHK(record_begin(ctx, s, ctx->ev_br));
-  switch (ctx->P.l) {
-    case 1: hipLaunchKernelGGL(k_blind_rotate<1>, grid, block, lds, s, A); break;
-    case 2: hipLaunchKernelGGL(k_blind_rotate<2>, grid, block, lds, s, A); break;
-    case 3: hipLaunchKernelGGL(k_blind_rotate<3>, grid, block, lds, s, A); break;
-    default: return fail(ctx, TFHE_HIP_EINVAL, "unsupported l");
+  // Launch in rounds of exactly the resident set: every workgroup of a round starts
+  // step 0 together and streams the bootstrapping key in near lock-step, so each key
+  // row is pulled from HBM / Infinity Cache into an XCD's L2 once per round instead of
+  // once per workgroup.  (One launch of the whole batch lets rounds drift apart and
+  // the 4 MiB L2s thrash: measured 1.5 TB fabric reads per 65,536 bootstraps.)
+  size_t chunk = count;
+  if (ctx->br_chunk > 0) chunk = (size_t)ctx->br_chunk;
+  if (ctx->br_chunk < 0) {
+    int per_cu = 0;
+    hipError_t e = hipErrorUnknown;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64, lds);
+    if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus;
   }
-  HIPCHK(ctx, hipGetLastError());
-  CHK(record_end(ctx, s, ctx->ev_br));
+  if (chunk == 0 || chunk > count) chunk = count;
+  for (size_t done = 0; done < count; done += chunk) {
+    const size_t m = (count - done < chunk) ? count - done : chunk;
+    BlindRotateArgs S = A;
+    S.in_a = A.in_a + done * (size_t)(ctx->P.n + 1);
+    if (A.in_b) S.in_b = A.in_b + done * (size_t)(ctx->P.n + 1);
+    S.testvec = A.testvec + done * A.per_ct_stride;
+    if (A.out_trlwe) S.out_trlwe = A.out_trlwe + done * (size_t)(2 * kN);
+    if (A.out_lv1) S.out_lv1 = A.out_lv1 + done * (size_t)(kN + 1);
+    if (A.out_ext2) S.out_ext2 = A.out_ext2 + done * (size_t)(ctx->P.n + 1);
+    dim3 grid((unsigned)m);
+    CHK(record_begin(ctx, s, ctx->ev_br));
+    hipLaunchKernelGGL(br_kernel(ctx), grid, block, lds, s, S);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_br));
+  }
   ctx->bootstraps += count;
   return TFHE_HIP_OK;
 }
@@ -174,17 +221,13 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
 int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
   if (count == 0) return TFHE_HIP_OK;
   const int n = ctx->P.n;
-  const int xc = (n + 1 > 1024) ? 2 : 1;
-  int bd = ((n + 1 + xc - 1) / xc + 63) & ~63;
+  const int rw4 = ksk_row_words(n) >> 2;
+  const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
   dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
-  size_t lds = (size_t)kKsG * kN * sizeof(uint32_t);
   CHK(record_begin(ctx, s, ctx->ev_ks));
-  if (xc == 1)
-    hipLaunchKernelGGL((k_key_switch<kKsG, 1>), grid, block, lds, s, lv1, ctx->d_ksk, n, ctx->P.basebit,
-                       ctx->P.t, out, count);
-  else
-    hipLaunchKernelGGL((k_key_switch<kKsG, 2>), grid, block, lds, s, lv1, ctx->d_ksk, n, ctx->P.basebit,
-                       ctx->P.t, out, count);
+  const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
+  hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->d_ksk, (uint32_t)ksk_bytes, n,
+                     ctx->P.basebit, ctx->P.t, out, count);
   HIPCHK(ctx, hipGetLastError());
   CHK(record_end(ctx, s, ctx->ev_ks));
   return TFHE_HIP_OK;
@@ -294,8 +337,9 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     return TFHE_HIP_EINVAL;
   }
   *out = nullptr;
-  if (p->n < 1 || p->n > 2047 || p->l < 1 || p->l > 3 || p->bgbit < 1 || p->l * p->bgbit > 32 ||
-      p->basebit < 1 || p->basebit > 10 || p->t < 1 || p->basebit * p->t > 31) {
+  if (p->n < 1 || p->n > 1279 || p->l < 1 || p->l > 3 || p->bgbit < 1 || p->l * p->bgbit > 32 ||
+      p->basebit < 1 || p->basebit > 10 || p->t < 1 || p->basebit * p->t > 31 ||
+      (double)kN * p->t * (double)(1u << p->basebit) * ksk_row_words(p->n) * 4.0 >= 4294967296.0) {
     g_create_error = "unsupported parameter set";
     return TFHE_HIP_EINVAL;
   }
@@ -320,6 +364,15 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", e);
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+  ctx->num_cus = prop.multiProcessorCount;
+  // pre-rounding magnitude bound: 2l polynomials x N terms x (Bg/2) digit x 2^31 key coefficient
+  ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
+  if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
+  if (const char *env = getenv("TFHE_HIP_BR_LDS_PAD")) ctx->br_lds_pad = (size_t)atol(env) & ~(size_t)15;
+  if (const char *env = getenv("TFHE_HIP_BR_WPS")) ctx->br_wps = atoi(env) == 1 ? 1 : 2;
   std::vector<double2> tw;
   make_twiddles(tw);
   if ((e = hipMalloc((void **)&ctx->d_tw, tw.size() * sizeof(double2))) != hipSuccess)
@@ -368,7 +421,8 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   const size_t ksk_words = (size_t)kN * P.t * base * (size_t)(P.n + 1);
   ctx->key_loaded = false;
   if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bsk_bytes));
-  if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, ksk_words * 4));
+  if (!ctx->d_ksk)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4));
   if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
   // bootstrapping key: upload the reference layout, permute + scale on the device
   double *d_ref = nullptr;
@@ -381,11 +435,20 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   (void)hipFree(d_ref);
   if (e != hipSuccess) return fail(ctx, TFHE_HIP_EHIP, std::string("bsk upload: ") + hipGetErrorString(e));
-  // key-switching key: reference layout, k == 0 rows forced to zero
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_ksk, ksk, ksk_words * 4, hipMemcpyHostToDevice, ctx->stream));
-  const size_t groups = (size_t)kN * P.t;
-  hipLaunchKernelGGL(k_ksk_zero_k0, dim3((unsigned)groups), dim3(256), 0, ctx->stream, ctx->d_ksk, P.n, base, groups);
-  HIPCHK(ctx, hipGetLastError());
+  // key-switching key: upload the reference layout, pad rows to 16 B and zero the k == 0 rows
+  {
+    const size_t rows = (size_t)kN * P.t * base;
+    uint32_t *d_kref = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&d_kref, ksk_words * 4));
+    hipError_t e2 = hipMemcpyAsync(d_kref, ksk, ksk_words * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e2 == hipSuccess) {
+      hipLaunchKernelGGL(k_ksk_convert, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_kref, ctx->d_ksk, P.n, base, rows);
+      e2 = hipGetLastError();
+    }
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_kref);
+    if (e2 != hipSuccess) return fail(ctx, TFHE_HIP_EHIP, std::string("ksk upload: ") + hipGetErrorString(e2));
+  }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, testvec, 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->offset = decomp_offset;
@@ -540,11 +603,9 @@ int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
   const uint32_t *in = (const uint32_t *)ctx->h_a.p;
   const int32_t *idx = (const int32_t *)ctx->h_idx.p;
   uint32_t *o = (uint32_t *)ctx->h_out.p;
-  switch (ctx->P.l) {
-    case 1: hipLaunchKernelGGL(k_external_product<1>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
-    case 2: hipLaunchKernelGGL(k_external_product<2>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
-    default: hipLaunchKernelGGL(k_external_product<3>, grid, block, kTileBytes, ctx->stream, in, idx, ctx->d_bsk, ctx->d_tw, ctx->P.bgbit, ctx->offset, o); break;
-  }
+  const uint32_t bsk_bytes = (uint32_t)((size_t)ctx->P.n * 2 * ctx->P.l * 2 * kN2 * 16);
+  hipLaunchKernelGGL(ep_kernel(ctx), grid, block, kStageLdsBytes, ctx->stream, in, idx, ctx->d_bsk, bsk_bytes, ctx->d_tw,
+                     ctx->P.bgbit, ctx->offset, o);
   HIPCHK(ctx, hipGetLastError());
   return to_host(ctx, trlwe_out, ctx->h_out, bytes);
 }
@@ -586,7 +647,7 @@ int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, siz
   HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 4));
   CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 8));
-  hipLaunchKernelGGL(k_ifft, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+  hipLaunchKernelGGL(k_ifft, dim3((unsigned)count), dim3(64), kStageLdsBytes, ctx->stream,
                      (const uint32_t *)ctx->h_a.p, ctx->d_tw, (double *)ctx->h_out.p);
   HIPCHK(ctx, hipGetLastError());
   return to_host(ctx, res, ctx->h_out, count * (size_t)kN * 8);
@@ -600,7 +661,7 @@ int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size
   HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 8));
   CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 4));
-  hipLaunchKernelGGL(k_fft, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+  hipLaunchKernelGGL(k_fft, dim3((unsigned)count), dim3(64), kStageLdsBytes, ctx->stream,
                      (const double *)ctx->h_a.p, ctx->d_tw, (uint32_t *)ctx->h_out.p);
   HIPCHK(ctx, hipGetLastError());
   return to_host(ctx, res, ctx->h_out, count * (size_t)kN * 4);
@@ -616,7 +677,7 @@ int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
   CHK(ensure(ctx, ctx->h_out, bytes));
-  hipLaunchKernelGGL(k_poly_mul, dim3((unsigned)count), dim3(64), kTileBytes, ctx->stream,
+  hipLaunchKernelGGL(k_poly_mul, dim3((unsigned)count), dim3(64), kStageLdsBytes, ctx->stream,
                      (const uint32_t *)ctx->h_a.p, (const uint32_t *)ctx->h_b.p, ctx->d_tw,
                      (uint32_t *)ctx->h_out.p);
   HIPCHK(ctx, hipGetLastError());
