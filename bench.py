@@ -139,14 +139,21 @@ def main():
     br_ms = kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"])
     ks_ms = kt["key_switch_ms"] / max(1, kt["key_switch_launches"])
     achieved = (br_bytes_per_ct * B) / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
+    traffic = None
+    try:  # PMC counters cannot be read live: take the committed per-launch figure for this exact workload
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm["config"] == {"params": args.params, "batch": B, "gate": args.gate}:
+            traffic = pm["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {
-        "kernel": "k_blind_rotate<3>",
+        "kernel": f"k_blind_rotate<{P.l}>",
         "bound": "hbm",
         "achieved": round(achieved, 1),
         "peak": 8000.0,
         "unit": "GB/s",
         "frac": round(achieved / 8000.0, 4),
-        "traffic": None,
+        "traffic": traffic,
         "algorithmic_bytes_per_launch": br_bytes_per_ct * B,
         "avg_launch_ms": round(br_ms, 3),
         "key_switch_avg_launch_ms": round(ks_ms, 3),
