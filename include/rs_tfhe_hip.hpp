@@ -1,0 +1,394 @@
+// rs_tfhe_hip.hpp -- C++ host-side mirror of the rs-tfhe API surface for the
+// gate-bootstrapping hot path, over the C ABI of tfhe_hip.h.
+//
+// The reference is a Rust crate and no Rust toolchain exists in this image, so
+// the host layer above the C ABI is written in C++ with the reference's names,
+// argument meaning and error behaviour (a Rust panic is a C++ exception here).
+// The Rust binding itself is given in INTEGRATION.md.
+//
+//   rs-tfhe (src/...)                          here (namespace rs_tfhe)
+//   params::SecurityParams / SECURITY_*        SecurityParams, SECURITY_128_BIT, ...
+//   utils::Ciphertext = tlwe::TLWELv0          Ciphertext   (p[0..n] = a, p[n] = b)
+//   trlwe::TRLWELv1                            TRLWELv1
+//   key::CloudKey                              CloudKey
+//   bootstrap::Bootstrap (trait)               Bootstrap (abstract class)
+//   bootstrap::vanilla::VanillaBootstrap       HipBootstrap  (same three methods)
+//   bootstrap::lut::LutBootstrap               LutBootstrap  (bootstrap_func, bootstrap_lut)
+//   lut::{Encoder, Generator, LookupTable}     lut::{Encoder, Generator, LookupTable}
+//   gates::Gates + free fns + batch_*          Gates, gates::nand..., gates::batch_nand...
+//   trgsw::batch_blind_rotate                  trgsw::batch_blind_rotate
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tfhe_hip.h"
+
+namespace rs_tfhe {
+
+using Torus = uint32_t;  // src/params.rs:40
+constexpr size_t N = TFHE_HIP_N;
+
+// ---- src/params.rs:53-84 ------------------------------------------------------
+struct SecurityParams {
+  int security_bits;
+  int n;        // tlwe_lv0.n
+  int l;        // trgsw_lv1.l
+  int bgbit;    // trgsw_lv1.bgbit
+  int basebit;  // trgsw_lv1.basebit
+  int iks_t;    // trgsw_lv1.iks_t
+  double alpha_lv0, alpha_lv1;
+  int base() const { return 1 << basebit; }
+  bool operator==(const SecurityParams &o) const {
+    return n == o.n && l == o.l && bgbit == o.bgbit && basebit == o.basebit && iks_t == o.iks_t;
+  }
+};
+constexpr SecurityParams SECURITY_80_BIT{80, 550, 3, 6, 2, 7, 5.0e-5, 3.73e-8};                 // params.rs:91-116
+constexpr SecurityParams SECURITY_110_BIT{110, 630, 3, 6, 2, 8, 3.0517578125e-05, 2.9802322387695313e-8};  // :119-144
+constexpr SecurityParams SECURITY_128_BIT{128, 700, 3, 6, 2, 9, 2.0e-5, 2.0e-8};                // :379-404
+constexpr SecurityParams SECURITY_UINT1{1, 700, 2, 10, 2, 8, 2.0e-05, 2.0e-08};                 // :148-173
+constexpr SecurityParams SECURITY_UINT4{4, 820, 1, 22, 5, 3, 0.0000025167616095979554, 2.220446049250313e-16};  // :235-260
+constexpr SecurityParams DEFAULT_SECURITY = SECURITY_128_BIT;                                    // :411
+
+// ---- src/utils.rs:9-16 -----------------------------------------------------------
+inline Torus f64_to_torus(double d) {
+  double t = std::fmod(d, 1.0) * 4294967296.0;
+  return (Torus)(int64_t)t;
+}
+inline double torus_to_f64(Torus t) { return (double)t / 4294967296.0; }
+
+// ---- src/tlwe.rs:12-35 (run-time n instead of the compile-time 128-bit alias) -----
+struct Ciphertext {
+  std::vector<Torus> p;
+  Ciphertext() = default;
+  explicit Ciphertext(int n) : p((size_t)n + 1, 0) {}
+  int n() const { return (int)p.size() - 1; }
+  Torus b() const { return p.back(); }
+  Torus &b_mut() { return p.back(); }
+};
+
+// ---- src/trlwe.rs:11-14 --------------------------------------------------------------
+struct TRLWELv1 {
+  std::array<Torus, N> a{};
+  std::array<Torus, N> b{};
+};
+
+// ---- src/key.rs:51-56 (flat layouts of tfhe_hip.h) --------------------------------------
+struct CloudKey {
+  SecurityParams params = DEFAULT_SECURITY;
+  Torus decomposition_offset = 0;
+  TRLWELv1 blind_rotate_testvec;
+  std::vector<Torus> key_switching_key;   // [N][t][base][n+1], index base*t*i + base*j + k
+  std::vector<double> bootstrapping_key;  // [n] TRGSWLv1FFT = [n][2l][2][N]
+};
+
+// key.rs:78-89
+inline Torus gen_decomposition_offset(const SecurityParams &p) {
+  Torus off = 0;
+  for (int i = 0; i < p.l; ++i) off += ((1u << p.bgbit) / 2) * (1u << (32 - (i + 1) * p.bgbit));
+  return off;
+}
+// key.rs:91-100
+inline TRLWELv1 gen_testvec() {
+  TRLWELv1 tv;
+  tv.b.fill(f64_to_torus(0.125));
+  return tv;
+}
+
+// ---- engine handle: one C-ABI context per (parameter set, device), key cached ----------------
+class Engine {
+ public:
+  Engine(const SecurityParams &p, int device) : params_(p) {
+    tfhe_hip_params cp{p.n, p.l, p.bgbit, p.basebit, p.iks_t};
+    int rc = tfhe_hip_ctx_create(&cp, device, &ctx_);
+    if (rc != TFHE_HIP_OK) throw std::runtime_error(std::string("tfhe_hip_ctx_create: ") + tfhe_hip_last_error(nullptr));
+  }
+  ~Engine() { tfhe_hip_ctx_destroy(ctx_); }
+  Engine(const Engine &) = delete;
+  Engine &operator=(const Engine &) = delete;
+
+  void ensure_key(const CloudKey &ck) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (loaded_ == &ck) return;  // `&CloudKey` identity, as the reference borrows it
+    const SecurityParams &p = params_;
+    if (ck.bootstrapping_key.size() != (size_t)p.n * 2 * p.l * 2 * N ||
+        ck.key_switching_key.size() != N * (size_t)p.iks_t * p.base() * (p.n + 1))
+      throw std::runtime_error("CloudKey does not match the parameter set");
+    check(tfhe_hip_load_cloud_key(ctx_, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
+                                  ck.decomposition_offset, ck.blind_rotate_testvec.a.data()));
+    loaded_ = &ck;
+  }
+  void check(int rc) const {
+    if (rc != TFHE_HIP_OK) throw std::runtime_error(std::string("tfhe_hip: ") + tfhe_hip_last_error(ctx_));
+  }
+  tfhe_hip_ctx *ctx() const { return ctx_; }
+  const SecurityParams &params() const { return params_; }
+
+  static Engine &for_key(const CloudKey &ck, int device = 0) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<Engine>> engines;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : engines)
+      if (e->params_ == ck.params && e->device_ == device) return *e;
+    engines.emplace_back(new Engine(ck.params, device));
+    engines.back()->device_ = device;
+    return *engines.back();
+  }
+
+ private:
+  SecurityParams params_;
+  tfhe_hip_ctx *ctx_ = nullptr;
+  const CloudKey *loaded_ = nullptr;
+  int device_ = 0;
+  std::mutex mu_;
+};
+
+namespace detail {
+inline std::vector<Torus> flatten(const std::vector<Ciphertext> &v, int n) {
+  std::vector<Torus> out(v.size() * (size_t)(n + 1));
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (v[i].n() != n) throw std::runtime_error("ciphertext dimension mismatch");
+    std::copy(v[i].p.begin(), v[i].p.end(), out.begin() + i * (size_t)(n + 1));
+  }
+  return out;
+}
+inline std::vector<Ciphertext> unflatten(const std::vector<Torus> &flat, size_t count, int n) {
+  std::vector<Ciphertext> out(count, Ciphertext(n));
+  for (size_t i = 0; i < count; ++i)
+    std::copy(flat.begin() + i * (size_t)(n + 1), flat.begin() + (i + 1) * (size_t)(n + 1), out[i].p.begin());
+  return out;
+}
+inline std::vector<Ciphertext> batch_gate(int gate, const std::vector<std::pair<Ciphertext, Ciphertext>> &inputs,
+                                          const CloudKey &ck, int device = 0) {
+  Engine &e = Engine::for_key(ck, device);
+  e.ensure_key(ck);
+  const int n = ck.params.n;
+  std::vector<Ciphertext> a, b;
+  a.reserve(inputs.size());
+  b.reserve(inputs.size());
+  for (auto &pr : inputs) {
+    a.push_back(pr.first);
+    b.push_back(pr.second);
+  }
+  auto fa = flatten(a, n), fb = flatten(b, n);
+  std::vector<Torus> out(fa.size());
+  e.check(tfhe_hip_batch_gate(e.ctx(), gate, fa.data(), fb.data(), out.data(), inputs.size()));
+  return unflatten(out, inputs.size(), n);
+}
+}  // namespace detail
+
+// ---- src/lut/{encoder,lookup_table,generator}.rs -------------------------------------------
+namespace lut {
+inline size_t div_round(size_t a, size_t b) { return (a + b / 2) / b; }  // generator.rs:264-266
+
+struct Encoder {  // encoder.rs:13-115
+  size_t message_modulus;
+  double scale;
+  explicit Encoder(size_t m) : message_modulus(m), scale(1.0 / (2.0 * (double)m)) {}
+  Encoder(size_t m, double s) : message_modulus(m), scale(s) {}
+  Torus encode(size_t message) const { return f64_to_torus((double)(message % message_modulus) * scale); }
+  size_t decode(Torus v) const { return (size_t)(torus_to_f64(v) / scale + 0.5) % message_modulus; }
+  bool decode_bool(Torus v) const { return decode(v) != 0; }
+};
+
+struct LookupTable {  // lookup_table.rs:16-19
+  TRLWELv1 poly;
+};
+
+class Generator {  // generator.rs:15-259
+ public:
+  explicit Generator(size_t message_modulus) : encoder_(message_modulus) {}
+  Generator(size_t message_modulus, double scale) : encoder_(message_modulus, scale) {}
+  size_t message_modulus() const { return encoder_.message_modulus; }
+  size_t poly_degree() const { return N; }
+  size_t lookup_table_size() const { return N; }
+
+  LookupTable generate_lookup_table(const std::function<size_t(size_t)> &f) const {  // :66-137
+    return assemble([&](size_t x) { return encoder_.encode(f(x)); });
+  }
+  LookupTable generate_lookup_table_full(const std::function<Torus(size_t)> &f) const {  // :146-203
+    return assemble(f);
+  }
+
+ private:
+  LookupTable assemble(const std::function<Torus(size_t)> &value) const {
+    const size_t m = encoder_.message_modulus, size = N;
+    std::vector<Torus> raw(size, 0), rot(size, 0);
+    for (size_t x = 0; x < m; ++x) {
+      size_t start = div_round(x * size, m), end = div_round((x + 1) * size, m);
+      Torus y = value(x);
+      for (size_t i = start; i < end && i < size; ++i) raw[i] = y;
+    }
+    const size_t offset = div_round(size, 2 * m);
+    for (size_t i = 0; i < size; ++i) rot[i] = raw[(i + offset) % size];
+    for (size_t i = size - offset; i < size; ++i) rot[i] = 0u - rot[i];  // wrapping_neg
+    LookupTable lut;
+    for (size_t i = 0; i < size; ++i) lut.poly.b[i] = rot[i];
+    return lut;
+  }
+  Encoder encoder_;
+};
+}  // namespace lut
+
+// ---- src/bootstrap/mod.rs:23-43 ---------------------------------------------------------------
+class Bootstrap {
+ public:
+  virtual ~Bootstrap() = default;
+  virtual Ciphertext bootstrap(const Ciphertext &ctxt, const CloudKey &cloud_key) const = 0;
+  virtual Ciphertext bootstrap_without_key_switch(const Ciphertext &ctxt, const CloudKey &cloud_key) const = 0;
+  virtual std::string name() const = 0;
+};
+
+// The GPU stand-in for VanillaBootstrap (src/bootstrap/vanilla.rs:22-69)
+class HipBootstrap : public Bootstrap {
+ public:
+  explicit HipBootstrap(int device = 0) : device_(device) {}
+  Ciphertext bootstrap(const Ciphertext &ctxt, const CloudKey &ck) const override {  // vanilla.rs:40-52
+    return run(ctxt, nullptr, 1, ck);
+  }
+  Ciphertext bootstrap_without_key_switch(const Ciphertext &ctxt, const CloudKey &ck) const override {  // :54-63
+    return run(ctxt, nullptr, 0, ck);
+  }
+  std::string name() const override { return tfhe_hip_name(); }
+  int device() const { return device_; }
+
+ protected:
+  Ciphertext run(const Ciphertext &ctxt, const TRLWELv1 *testvec, int keyswitch, const CloudKey &ck) const {
+    Engine &e = Engine::for_key(ck, device_);
+    e.ensure_key(ck);
+    if (ctxt.n() != ck.params.n) throw std::runtime_error("ciphertext dimension mismatch");
+    Ciphertext out(ck.params.n);
+    e.check(tfhe_hip_batch_bootstrap(e.ctx(), ctxt.p.data(), testvec ? testvec->a.data() : nullptr, 0, keyswitch,
+                                     out.p.data(), 1));
+    return out;
+  }
+  int device_;
+};
+
+// src/bootstrap/lut.rs:24-126
+class LutBootstrap : public HipBootstrap {
+ public:
+  using HipBootstrap::HipBootstrap;
+  Ciphertext bootstrap_func(const Ciphertext &ct_in, const std::function<size_t(size_t)> &f, size_t message_modulus,
+                            const CloudKey &ck) const {  // lut.rs:49-65
+    return bootstrap_lut(ct_in, lut::Generator(message_modulus).generate_lookup_table(f), ck);
+  }
+  Ciphertext bootstrap_lut(const Ciphertext &ct_in, const lut::LookupTable &lut, const CloudKey &ck) const {  // :79-99
+    static_assert(sizeof(TRLWELv1) == 2 * N * sizeof(Torus), "TRLWELv1 must be a||b contiguous");
+    return run(ct_in, &lut.poly, 1, ck);
+  }
+  Ciphertext bootstrap(const Ciphertext &ctxt, const CloudKey &ck) const override {  // lut.rs:108-111
+    return bootstrap_func(ctxt, [](size_t x) { return x; }, 2, ck);
+  }
+  Ciphertext bootstrap_without_key_switch(const Ciphertext &ctxt, const CloudKey &ck) const override {  // :113-121
+    return bootstrap(ctxt, ck);
+  }
+  std::string name() const override { return std::string("lut-") + tfhe_hip_name(); }
+};
+
+inline std::unique_ptr<Bootstrap> default_bootstrap() {  // bootstrap/mod.rs:41-43
+  return std::unique_ptr<Bootstrap>(new HipBootstrap());
+}
+
+// ---- src/gates.rs:30-219 -----------------------------------------------------------------------
+class Gates {
+ public:
+  Gates() : bootstrap_(default_bootstrap()), fused_(true) {}
+  static Gates with_bootstrap(std::unique_ptr<Bootstrap> b) {  // gates.rs:43-45
+    Gates g;
+    g.fused_ = dynamic_cast<HipBootstrap *>(b.get()) && !dynamic_cast<LutBootstrap *>(b.get());
+    g.bootstrap_ = std::move(b);
+    return g;
+  }
+  std::string bootstrap_strategy() const { return bootstrap_->name(); }  // gates.rs:48-50
+
+  Ciphertext nand(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_NAND, -1, -1, 0.125, a, b, k); }
+  Ciphertext or_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_OR, 1, 1, 0.125, a, b, k); }
+  Ciphertext and_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_AND, 1, 1, -0.125, a, b, k); }
+  Ciphertext xor_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_XOR, 1, 2, 0.25, a, b, k); }
+  Ciphertext xnor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_XNOR, 1, -2, -0.25, a, b, k); }
+  Ciphertext nor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_NOR, -1, -1, -0.125, a, b, k); }
+  Ciphertext and_ny(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_ANDNY, -1, 1, -0.125, a, b, k); }
+  Ciphertext and_yn(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_ANDYN, 1, -1, -0.125, a, b, k); }
+  Ciphertext or_ny(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_ORNY, -1, 1, 0.125, a, b, k); }
+  Ciphertext or_yn(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const { return run(TFHE_HIP_ORYN, 1, -1, 0.125, a, b, k); }
+
+  Ciphertext mux(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) const {  // :157-183
+    return mux_impl(0, a, b, c, k);
+  }
+  Ciphertext mux_naive(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) const {  // :189-199
+    return mux_impl(1, a, b, c, k);
+  }
+  Ciphertext not_(const Ciphertext &a) const {  // gates.rs:202-204
+    Ciphertext r = a;
+    for (auto &x : r.p) x = 0u - x;
+    return r;
+  }
+  Ciphertext copy(const Ciphertext &a) const { return a; }  // gates.rs:207-209
+  Ciphertext constant(bool value, int n) const {            // gates.rs:212-219 (1 - mu wraps: quirk Q6)
+    Torus mu = f64_to_torus(0.125);
+    mu = value ? mu : 1u - mu;
+    Ciphertext r(n);
+    r.b_mut() = mu;
+    return r;
+  }
+
+ private:
+  Ciphertext run(int gate, int ca, int cb, double cst, const Ciphertext &a, const Ciphertext &b, const CloudKey &k) const {
+    if (fused_) return detail::batch_gate(gate, {{a, b}}, k)[0];
+    Ciphertext t(a.n());  // any other strategy: linear prep here, then its bootstrap()
+    for (size_t i = 0; i < t.p.size(); ++i) t.p[i] = (Torus)ca * a.p[i] + (Torus)cb * b.p[i];
+    t.b_mut() += f64_to_torus(cst);
+    return bootstrap_->bootstrap(t, k);
+  }
+  Ciphertext mux_impl(int naive, const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) const {
+    Engine &e = Engine::for_key(k);
+    e.ensure_key(k);
+    Ciphertext out(k.params.n);
+    e.check(tfhe_hip_batch_mux(e.ctx(), naive, a.p.data(), b.p.data(), c.p.data(), out.p.data(), 1));
+    return out;
+  }
+  std::unique_ptr<Bootstrap> bootstrap_;
+  bool fused_;
+};
+
+// ---- src/gates.rs:233-326 (free fns) and :352-547 (batch fns) --------------------------------------
+namespace gates {
+inline Ciphertext nand(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().nand(a, b, k); }
+inline Ciphertext or_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().or_(a, b, k); }
+inline Ciphertext and_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().and_(a, b, k); }
+inline Ciphertext xor_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().xor_(a, b, k); }
+inline Ciphertext xnor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().xnor(a, b, k); }
+inline Ciphertext nor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().nor(a, b, k); }
+inline Ciphertext mux_naive(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) {
+  return Gates().mux_naive(a, b, c, k);
+}
+using Pairs = std::vector<std::pair<Ciphertext, Ciphertext>>;
+inline std::vector<Ciphertext> batch_nand(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_NAND, in, k); }
+inline std::vector<Ciphertext> batch_and(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_AND, in, k); }
+inline std::vector<Ciphertext> batch_or(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_OR, in, k); }
+inline std::vector<Ciphertext> batch_xor(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_XOR, in, k); }
+inline std::vector<Ciphertext> batch_nor(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_NOR, in, k); }
+inline std::vector<Ciphertext> batch_xnor(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_XNOR, in, k); }
+}  // namespace gates
+
+// ---- src/trgsw.rs:289-294 ----------------------------------------------------------------------------
+namespace trgsw {
+inline std::vector<TRLWELv1> batch_blind_rotate(const std::vector<Ciphertext> &srcs, const CloudKey &ck) {
+  Engine &e = Engine::for_key(ck);
+  e.ensure_key(ck);
+  auto flat = detail::flatten(srcs, ck.params.n);
+  std::vector<TRLWELv1> out(srcs.size());
+  e.check(tfhe_hip_batch_blind_rotate(e.ctx(), flat.data(), nullptr, out.empty() ? nullptr : out[0].a.data(), srcs.size()));
+  return out;
+}
+}  // namespace trgsw
+
+}  // namespace rs_tfhe

@@ -1,0 +1,165 @@
+// C++ host-mirror tests, written after the reference's own unit tests
+// (src/gates.rs:559-681, 832-858; src/bootstrap/vanilla.rs:78-141; src/bootstrap/lut.rs:142-254).
+// Key material and decryption come from the CPU oracle (test infrastructure); everything
+// under test goes through include/rs_tfhe_hip.hpp -> the C ABI -> the HIP kernels.
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+
+#include "rs_tfhe_hip.hpp"
+
+extern "C" {
+typedef struct {
+  int32_t n, l, bgbit, basebit, t;
+  double alpha_lv0, alpha_lv1;
+} orc_params;
+void orc_init(void);
+void orc_gen_secret_key(uint64_t seed, int n, uint32_t *key_lv0, uint32_t *key_lv1);
+void orc_gen_bootstrapping_key(uint64_t seed, const orc_params *P, const uint32_t *k0, const uint32_t *k1,
+                               double *bsk_fft, uint32_t *bsk_time);
+void orc_gen_key_switching_key(uint64_t seed, const orc_params *P, const uint32_t *k0, const uint32_t *k1,
+                               uint32_t *ksk);
+void orc_tlwe_encrypt_f64(uint64_t seed, double p, double alpha, const uint32_t *key, int dim, uint32_t *out);
+int orc_tlwe_decrypt_bool(const uint32_t *ct, const uint32_t *key, int dim);
+int orc_tlwe_decrypt_lwe_message(const uint32_t *ct, int m, const uint32_t *key, int dim);
+}
+
+using namespace rs_tfhe;
+
+static int failures = 0;
+#define CHECK(cond, ...)                              \
+  do {                                                \
+    if (!(cond)) {                                    \
+      ++failures;                                     \
+      std::printf("FAIL %s:%d: ", __FILE__, __LINE__); \
+      std::printf(__VA_ARGS__);                       \
+      std::printf("\n");                              \
+    }                                                 \
+  } while (0)
+
+struct SecretKey {  // key::SecretKey (src/key.rs:21-49)
+  std::vector<Torus> key_lv0, key_lv1;
+};
+
+static uint64_t g_seed = 1;
+static Ciphertext encrypt_bool(bool b, const SecurityParams &P, const SecretKey &sk) {  // tlwe.rs:55-58
+  Ciphertext c(P.n);
+  orc_tlwe_encrypt_f64(g_seed++, b ? 0.125 : -0.125, P.alpha_lv0, sk.key_lv0.data(), P.n, c.p.data());
+  return c;
+}
+static Ciphertext encrypt_lwe_message(size_t m, size_t modulus, const SecurityParams &P, const SecretKey &sk) {  // tlwe.rs:84-98
+  Ciphertext c(P.n);
+  orc_tlwe_encrypt_f64(g_seed++, (double)(m % modulus) / (2.0 * modulus), P.alpha_lv0, sk.key_lv0.data(), P.n, c.p.data());
+  return c;
+}
+static bool decrypt_bool(const Ciphertext &c, const SecretKey &sk) {
+  return orc_tlwe_decrypt_bool(c.p.data(), sk.key_lv0.data(), c.n()) != 0;
+}
+
+// gates.rs:832-858 `test_gate`
+static void test_gate(const char *name, const std::function<bool(bool, bool)> &expect,
+                      const std::function<Ciphertext(const Gates &, const Ciphertext &, const Ciphertext &, const CloudKey &)> &actual,
+                      const SecretKey &key, const CloudKey &cloud_key) {
+  Gates gates;
+  const bool cases[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
+  for (auto &tc : cases) {
+    Ciphertext ct_a = encrypt_bool(tc[0], cloud_key.params, key);
+    Ciphertext ct_b = encrypt_bool(tc[1], cloud_key.params, key);
+    Ciphertext result = actual(gates, ct_a, ct_b, cloud_key);
+    CHECK(decrypt_bool(result, key) == expect(tc[0], tc[1]), "%s failed for %d %d", name, tc[0], tc[1]);
+  }
+}
+
+int main() {
+  orc_init();
+  const SecurityParams P = SECURITY_128_BIT;
+  orc_params OP{P.n, P.l, P.bgbit, P.basebit, P.iks_t, P.alpha_lv0, P.alpha_lv1};
+  SecretKey key;
+  key.key_lv0.resize(P.n);
+  key.key_lv1.resize(N);
+  orc_gen_secret_key(99, P.n, key.key_lv0.data(), key.key_lv1.data());
+  CloudKey cloud_key;
+  cloud_key.params = P;
+  cloud_key.decomposition_offset = gen_decomposition_offset(P);
+  cloud_key.blind_rotate_testvec = gen_testvec();
+  cloud_key.bootstrapping_key.resize((size_t)P.n * 2 * P.l * 2 * N);
+  cloud_key.key_switching_key.resize(N * (size_t)P.iks_t * P.base() * (P.n + 1));
+  orc_gen_bootstrapping_key(199, &OP, key.key_lv0.data(), key.key_lv1.data(), cloud_key.bootstrapping_key.data(), nullptr);
+  orc_gen_key_switching_key(200, &OP, key.key_lv0.data(), key.key_lv1.data(), cloud_key.key_switching_key.data());
+  CHECK(cloud_key.decomposition_offset == 0x82080000u, "decomposition offset");
+
+  // gates.rs:559-653
+  test_gate("nand", [](bool a, bool b) { return !(a & b); }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.nand(a, b, k); }, key, cloud_key);
+  test_gate("or", [](bool a, bool b) { return a | b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.or_(a, b, k); }, key, cloud_key);
+  test_gate("and", [](bool a, bool b) { return a & b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.and_(a, b, k); }, key, cloud_key);
+  test_gate("xor", [](bool a, bool b) { return a ^ b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.xor_(a, b, k); }, key, cloud_key);
+  test_gate("xnor", [](bool a, bool b) { return false ^ (b ^ a); },  // sic, gates.rs:576-582
+            [](const Gates &g, auto &a, auto &b, auto &k) { return g.xnor(a, b, k); }, key, cloud_key);
+  test_gate("nor", [](bool a, bool b) { return !(a | b); }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.nor(a, b, k); }, key, cloud_key);
+  test_gate("and_ny", [](bool a, bool b) { return !a & b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.and_ny(a, b, k); }, key, cloud_key);
+  test_gate("and_yn", [](bool a, bool b) { return a & !b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.and_yn(a, b, k); }, key, cloud_key);
+  test_gate("or_ny", [](bool a, bool b) { return !a | b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.or_ny(a, b, k); }, key, cloud_key);
+  test_gate("or_yn", [](bool a, bool b) { return a | !b; }, [](const Gates &g, auto &a, auto &b, auto &k) { return g.or_yn(a, b, k); }, key, cloud_key);
+  test_gate("not", [](bool a, bool) { return !a; }, [](const Gates &g, auto &a, auto &, auto &) { return g.not_(a); }, key, cloud_key);
+  test_gate("copy", [](bool a, bool) { return a; }, [](const Gates &g, auto &a, auto &, auto &) { return g.copy(a); }, key, cloud_key);
+
+  // gates.rs:656-681 test_mux (mux_naive)
+  {
+    Gates gates;
+    for (int v = 0; v < 8; ++v) {
+      bool a = v & 4, b = v & 2, c = v & 1;
+      Ciphertext r = gates.mux_naive(encrypt_bool(a, P, key), encrypt_bool(b, P, key), encrypt_bool(c, P, key), cloud_key);
+      CHECK(decrypt_bool(r, key) == (a ? b : c), "mux_naive %d %d %d", a, b, c);
+    }
+  }
+  // gates.rs:352-383 batch_nand
+  {
+    gates::Pairs in;
+    const bool cases[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
+    for (int rep = 0; rep < 3; ++rep)
+      for (auto &tc : cases) in.push_back({encrypt_bool(tc[0], P, key), encrypt_bool(tc[1], P, key)});
+    auto out = gates::batch_nand(in, cloud_key);
+    CHECK(out.size() == in.size(), "batch size");
+    for (size_t i = 0; i < out.size(); ++i) CHECK(decrypt_bool(out[i], key) == !(cases[i % 4][0] && cases[i % 4][1]), "batch_nand %zu", i);
+    CHECK(gates::batch_nand({}, cloud_key).empty(), "empty batch");
+  }
+  // vanilla.rs:78-98 / :127-141 bootstrap through the trait object
+  {
+    std::unique_ptr<Bootstrap> bs = default_bootstrap();
+    CHECK(bs->name() == "hip-gfx950", "strategy name %s", bs->name().c_str());
+    for (bool v : {true, false}) CHECK(decrypt_bool(bs->bootstrap(encrypt_bool(v, P, key), cloud_key), key) == v, "bootstrap %d", v);
+    Ciphertext h = bs->bootstrap_without_key_switch(encrypt_bool(true, P, key), cloud_key);  // vanilla.rs:100-125: no-panic only
+    CHECK(h.n() == P.n, "bootstrap_without_key_switch shape");
+  }
+  // lut.rs:142-254 identity / NOT / constant / LUT reuse, message_modulus = 2
+  {
+    LutBootstrap lb;
+    for (size_t m : {0u, 1u}) {
+      Ciphertext ct = encrypt_lwe_message(m, 2, P, key);
+      auto dec = [&](const Ciphertext &c) { return (size_t)orc_tlwe_decrypt_lwe_message(c.p.data(), 2, key.key_lv0.data(), P.n); };
+      CHECK(dec(lb.bootstrap_func(ct, [](size_t x) { return x; }, 2, cloud_key)) == m, "lut identity");
+      CHECK(dec(lb.bootstrap_func(ct, [](size_t x) { return 1 - x; }, 2, cloud_key)) == 1 - m, "lut not");
+      CHECK(dec(lb.bootstrap_func(ct, [](size_t) { return (size_t)1; }, 2, cloud_key)) == 1, "lut const");
+      lut::LookupTable table = lut::Generator(2).generate_lookup_table([](size_t x) { return 1 - x; });
+      CHECK(dec(lb.bootstrap_lut(ct, table, cloud_key)) == 1 - m, "lut reuse");
+    }
+    CHECK(lb.name() == "lut-hip-gfx950", "lut name");
+  }
+  // error behaviour: the reference panics; here a std::runtime_error
+  {
+    bool threw = false;
+    try {
+      Gates().nand(Ciphertext(3), Ciphertext(3), cloud_key);
+    } catch (const std::runtime_error &) {
+      threw = true;
+    }
+    CHECK(threw, "dimension mismatch must throw");
+  }
+  // trgsw.rs:289-294
+  {
+    auto r = trgsw::batch_blind_rotate({encrypt_bool(true, P, key), encrypt_bool(false, P, key)}, cloud_key);
+    CHECK(r.size() == 2, "batch_blind_rotate size");
+  }
+  std::printf(failures ? "%d FAILURES\n" : "all C++ mirror tests passed (%d failures)\n", failures);
+  return failures ? 1 : 0;
+}

@@ -1,0 +1,25 @@
+"""C++ host mirror (include/rs_tfhe_hip.hpp): compiles on CPU; its reference-style test
+program (tests/cpp/test_mirror.cpp) runs on the GPU through the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def test_cpp_mirror_builds():
+    subprocess.check_call(["make", "-C", CPP])
+    assert os.path.exists(os.path.join(CPP, "build", "test_mirror"))
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_runs_on_gpu():
+    exe = os.path.join(CPP, "build", "test_mirror")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", CPP])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "all C++ mirror tests passed" in r.stdout
