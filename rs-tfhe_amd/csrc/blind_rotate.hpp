@@ -63,16 +63,35 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 constexpr int kPrefetchA = TFHE_PREFETCH_A;
 constexpr int kPrefetchB = TFHE_PREFETCH_B;
 
+// Signed bit-field extract (v_bfe_i32).  Written as inline asm on purpose: with
+// __builtin_amdgcn_sbfe and a run-time width, hipcc (ROCm 7.2 / clang 22) turns the following
+// int->double conversion into v_cvt_f64_U32 (it assumes the result non-negative), which
+// silently corrupts every negative digit.  The asm statement is opaque to that fold.
+__device__ __forceinline__ int32_t sbfe(uint32_t src, int shift, int width) {
+  int32_t d;
+  asm("v_bfe_i32 %0, %1, %2, %3" : "=v"(d) : "v"(src), "s"(shift), "v"(width));
+  return d;
+}
+
 template <int L>
 __device__ __forceinline__ void external_product_half(int half_sel, const uint32_t (&t_lo)[8],
                                                       const uint32_t (&t_hi)[8],
                                                       __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
                                                       const Twiddles &tw, double2 *tile, int lane, int bgbit,
-                                                      double (&fa_re)[8], double (&fa_im)[8],
-                                                      double (&fb_re)[8], double (&fb_im)[8]) {
+                                                      uint32_t signmask, double (&fa_re)[8],
+                                                      double (&fa_im)[8], double (&fb_re)[8],
+                                                      double (&fb_im)[8]) {
   const uint32_t lane_off = (uint32_t)lane * 16u;
-  const uint32_t mask = (1u << bgbit) - 1u;
-  const int32_t half = 1 << (bgbit - 1);
+  // digit_i = ((t >> shift_i) & (Bg-1)) - Bg/2  (trgsw.rs:162) = the sign-extended bgbit-wide
+  // field of t ^ sum_i (Bg/2 << shift_i): flipping a field's top bit is subtracting Bg/2 mod Bg.
+  // That sum is the decomposition offset itself (key.rs:78-89), so one XOR per coefficient
+  // turns every digit into a single signed bit-field extract.
+  uint32_t w_lo[8], w_hi[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    w_lo[m] = t_lo[m] ^ signmask;
+    w_hi[m] = t_hi[m] ^ signmask;
+  }
 #pragma unroll 1
   for (int i = 0; i < L; ++i) {
     const int r = half_sel * L + i;
@@ -89,8 +108,8 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
     double re[8], im[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      re[m] = (double)((int32_t)((t_lo[m] >> shift) & mask) - half);
-      im[m] = (double)((int32_t)((t_hi[m] >> shift) & mask) - half);
+      re[m] = (double)sbfe(w_lo[m], shift, bgbit);
+      im[m] = (double)sbfe(w_hi[m], shift, bgbit);
     }
     fft_forward(re, im, tw, tile, lane);
     // the rest of the row is fetched behind the first MACs
@@ -183,6 +202,9 @@ __global__ __launch_bounds__(64, WPS) void k_blind_rotate(BlindRotateArgs A) {
   const __amdgpu_buffer_rsrc_t bsk_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)A.bsk, 0, (int)((uint32_t)n * per_i_bytes), 0x00020000);
   const uint32_t offset = A.offset;
+  uint32_t signmask = 0;  // sum_i (Bg/2) << (32 - (i+1)*bgbit): the top bit of every digit field
+#pragma unroll
+  for (int i = 0; i < L; ++i) signmask |= 1u << (32 - i * A.bgbit - 1);
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int k = s_abar[i];
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(64, WPS) void k_blind_rotate(BlindRotateArgs A) {
         t_hi[m] = rot_read(p, j + kN2, k) - p[j + kN2] + offset;
       }
       external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane,
-                               A.bgbit, fa_re, fa_im, fb_re, fb_im);
+                               A.bgbit, signmask, fa_re, fa_im, fb_re, fb_im);
     }
     fft_inverse(fa_re, fa_im, tw, tile, lane);
 #pragma unroll
@@ -263,6 +285,9 @@ __global__ __launch_bounds__(64) void k_external_product(const uint32_t *in, con
   const __amdgpu_buffer_rsrc_t bsk_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void *)bsk, 0, (int)bsk_bytes, 0x00020000);
   const uint32_t idx = (uint32_t)__builtin_amdgcn_readfirstlane(bsk_index[ct]);
+  uint32_t signmask = 0;
+#pragma unroll
+  for (int i = 0; i < L; ++i) signmask |= 1u << (32 - i * bgbit - 1);
   double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
 #pragma unroll
   for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
@@ -275,8 +300,8 @@ __global__ __launch_bounds__(64) void k_external_product(const uint32_t *in, con
       t_lo[m] = p[lane + 64 * m] + offset;
       t_hi[m] = p[lane + 64 * m + kN2] + offset;
     }
-    external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, fa_re, fa_im,
-                             fb_re, fb_im);
+    external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, signmask,
+                             fa_re, fa_im, fb_re, fb_im);
   }
   uint32_t *o = out + ct * (size_t)(2 * kN);
   fft_inverse(fa_re, fa_im, tw, tile, lane);

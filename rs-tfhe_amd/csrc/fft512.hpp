@@ -79,6 +79,9 @@ struct Twiddles {
 };
 
 // In-register 8-point DFT.  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
+// The two 1/sqrt2 twiddles are not applied where they arise: their common factor H is
+// carried to the last stage and folded into its add/sub as FMAs (X = b +- H*q), which
+// removes the four H multiplies per butterfly.
 template <bool INV>
 __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
   constexpr double H = 0.70710678118654752440084436210485;
@@ -90,21 +93,16 @@ __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
   double t6r = re[2] - re[6], t6i = im[2] - im[6];
   double a3r = re[3] + re[7], a3i = im[3] + im[7];
   double t7r = re[3] - re[7], t7i = im[3] - im[7];
-  double a5r, a5i, a6r, a6i, a7r, a7i;
+  // p5 = t5 * (1 -+ i), p7 = t7 * (-1 -+ i)   (a5 = H*p5, a7 = H*p7), a6 = t6 * (-+i)
+  double p5r, p5i, a6r, a6i, p7r, p7i;
   if (!INV) {
-    a5r = (t5r + t5i) * H;   // * (1 - i)/sqrt2
-    a5i = (t5i - t5r) * H;
-    a6r = t6i;               // * -i
-    a6i = -t6r;
-    a7r = (t7i - t7r) * H;   // * (-1 - i)/sqrt2
-    a7i = -(t7r + t7i) * H;
+    p5r = t5r + t5i;  p5i = t5i - t5r;
+    a6r = t6i;        a6i = -t6r;
+    p7r = t7i - t7r;  p7i = -(t7r + t7i);
   } else {
-    a5r = (t5r - t5i) * H;   // * (1 + i)/sqrt2
-    a5i = (t5r + t5i) * H;
-    a6r = -t6i;              // * +i
-    a6i = t6r;
-    a7r = -(t7r + t7i) * H;  // * (-1 + i)/sqrt2
-    a7i = (t7r - t7i) * H;
+    p5r = t5r - t5i;  p5i = t5r + t5i;
+    a6r = -t6i;       a6i = t6r;
+    p7r = -(t7r + t7i);  p7i = t7r - t7i;
   }
   // even half
   double b0r = a0r + a2r, b0i = a0i + a2i;
@@ -113,21 +111,21 @@ __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
   double u3r = a1r - a3r, u3i = a1i - a3i;
   double b3r, b3i;
   if (!INV) { b3r = u3i; b3i = -u3r; } else { b3r = -u3i; b3i = u3r; }
-  // odd half
+  // odd half: b5 = H*q5 with q5 = p5 + p7; b7 = H*q7 with q7 = (p5 - p7) * (-+i)
   double b4r = a4r + a6r, b4i = a4i + a6i;
   double b6r = a4r - a6r, b6i = a4i - a6i;
-  double b5r = a5r + a7r, b5i = a5i + a7i;
-  double u7r = a5r - a7r, u7i = a5i - a7i;
-  double b7r, b7i;
-  if (!INV) { b7r = u7i; b7i = -u7r; } else { b7r = -u7i; b7i = u7r; }
+  double q5r = p5r + p7r, q5i = p5i + p7i;
+  double u7r = p5r - p7r, u7i = p5i - p7i;
+  double q7r, q7i;
+  if (!INV) { q7r = u7i; q7i = -u7r; } else { q7r = -u7i; q7i = u7r; }
   re[0] = b0r + b1r; im[0] = b0i + b1i;
   re[4] = b0r - b1r; im[4] = b0i - b1i;
   re[2] = b2r + b3r; im[2] = b2i + b3i;
   re[6] = b2r - b3r; im[6] = b2i - b3i;
-  re[1] = b4r + b5r; im[1] = b4i + b5i;
-  re[5] = b4r - b5r; im[5] = b4i - b5i;
-  re[3] = b6r + b7r; im[3] = b6i + b7i;
-  re[7] = b6r - b7r; im[7] = b6i - b7i;
+  re[1] = fma(H, q5r, b4r);  im[1] = fma(H, q5i, b4i);
+  re[5] = fma(-H, q5r, b4r); im[5] = fma(-H, q5i, b4i);
+  re[3] = fma(H, q7r, b6r);  im[3] = fma(H, q7i, b6i);
+  re[7] = fma(-H, q7r, b6r); im[7] = fma(-H, q7i, b6i);
 }
 
 // x *= (wr + i*wi)  or, CONJ, x *= (wr - i*wi)
