@@ -199,8 +199,22 @@ def main():
         t1 = time.perf_counter()
         ref = O.batch_gate(ock, gate, ca[:sample], cb[:sample])
         cpu_s = time.perf_counter() - t1
+        # BASELINE configs[0]: one hom_nand gate on one core (criterion gate_nand, benches/gate_benchmarks.rs:12-20)
+        t1 = time.perf_counter()
+        for r_ in range(3):
+            O.batch_gate(ock, gate, ca[r_:r_ + 1], cb[r_:r_ + 1], nthreads=1)
+        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+        O.batch_gate(ock, gate, ca[:1], cb[:1], nthreads=threads)  # restore the OpenMP team size
+        # the same single gate through the GPU path (host buffers, includes PCIe + sync)
+        eng.batch_gate(gate, ca[:1], cb[:1])
+        t1 = time.perf_counter()
+        for r_ in range(5):
+            eng.batch_gate(gate, ca[r_:r_ + 1], cb[r_:r_ + 1])
+        gpu_single_ms = (time.perf_counter() - t1) / 5 * 1e3
         cpu = {
             "value": round(sample / cpu_s, 2),
+            "single_gate_ms_1core": round(single_ms, 2),
+            "gpu_single_gate_ms": round(gpu_single_ms, 2),
             "unit": "bootstraps/s",
             "cores": threads,
             "kind": "port",
