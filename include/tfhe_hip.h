@@ -28,7 +28,8 @@
  *
  * Pointers are HOST pointers unless the function name ends in _dev, in which
  * case they are device pointers on the context's GPU and the call is enqueued
- * on `stream` (a hipStream_t passed as void*; NULL = the context's own stream)
+ * on `stream` (a hipStream_t passed as void*; NULL = the context's own non-blocking
+ * stream; pass hipStreamLegacy, i.e. (hipStream_t)1, to name the default stream)
  * without synchronising.
  *
  * Thread safety: a context may be used from several host threads (the
@@ -119,6 +120,16 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
                         uint32_t *out, size_t count);
 int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
                             uint32_t *out, size_t count, void *stream);
+
+/* A batch whose ciphertexts carry different gates: gates[c] is the tfhe_hip_gate of
+ * ciphertext pair c.  This is what a levelised circuit (e.g. the ripple-carry adder of
+ * examples/add_two_numbers.rs) issues per level: every gate of the level in ONE launch,
+ * whatever its type.  Same semantics as count calls of the Gates method
+ * (src/gates.rs:54-150); b is read for every gate but COPY. */
+int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
+                               const uint32_t *b, uint32_t *out, size_t count);
+int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
+                                   const uint32_t *b, uint32_t *out, size_t count, void *stream);
 
 /* Replaces: Bootstrap::bootstrap / bootstrap_without_key_switch
  * (src/bootstrap/vanilla.rs:40-63) and LutBootstrap::bootstrap_lut

@@ -51,6 +51,8 @@ SIGNATURES = {
     "tfhe_hip_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
     "tfhe_hip_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_batch_gates_mixed": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_gates_mixed_dev": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_bootstrap": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ]),
     "tfhe_hip_batch_bootstrap_dev": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ, _P]),
     "tfhe_hip_batch_blind_rotate": (C.c_int, [_CTX, _P, _P, _P, _SZ]),

@@ -1,0 +1,137 @@
+"""Levelised gate circuits with device-resident ciphertexts.
+
+The reference's real workloads are gate DAGs evaluated one gate at a time on the CPU
+(examples/add_two_numbers.rs:11-50: full_adder / add).  Here a circuit is built once as a DAG
+over wires, levelised, and every level -- all of its gates, whatever their types, times the
+whole batch of independent inputs -- is ONE `tfhe_hip_batch_gates_mixed_dev` launch.  Wires
+stay in HBM between levels; only the operand gather (an index_select) sits between launches.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import engine as E
+
+
+@dataclass
+class _Gate:
+    op: int
+    a: int
+    b: int
+    out: int
+    level: int
+
+
+@dataclass
+class Circuit:
+    n_inputs: int
+    gates: list = field(default_factory=list)
+    _level: dict = field(default_factory=dict)
+    _n_wires: int = 0
+
+    def __post_init__(self):
+        self._n_wires = self.n_inputs
+        for w in range(self.n_inputs):
+            self._level[w] = 0
+
+    # -- construction ----------------------------------------------------------------
+    def gate(self, op: int, a: int, b: int) -> int:
+        """A bootstrapped two-input gate (one of tfhe_hip_gate); returns its output wire."""
+        out = self._n_wires
+        self._n_wires += 1
+        lvl = 1 + max(self._level[a], self._level[b])
+        self._level[out] = lvl
+        self.gates.append(_Gate(op, a, b, out, lvl))
+        return out
+
+    def nand(self, a, b): return self.gate(E.NAND, a, b)
+    def and_(self, a, b): return self.gate(E.AND, a, b)
+    def or_(self, a, b): return self.gate(E.OR, a, b)
+    def xor(self, a, b): return self.gate(E.XOR, a, b)
+    def xnor(self, a, b): return self.gate(E.XNOR, a, b)
+    def nor(self, a, b): return self.gate(E.NOR, a, b)
+    def and_ny(self, a, b): return self.gate(E.ANDNY, a, b)
+    def and_yn(self, a, b): return self.gate(E.ANDYN, a, b)
+    def or_ny(self, a, b): return self.gate(E.ORNY, a, b)
+    def or_yn(self, a, b): return self.gate(E.ORYN, a, b)
+
+    def mux_naive(self, a, b, c):
+        """Gates::mux_naive (src/gates.rs:189-199): or(and(a, b), and(not(a), c))."""
+        return self.or_(self.and_(a, b), self.and_ny(a, c))
+
+    def full_adder(self, a, b, c):
+        """examples/add_two_numbers.rs:11-29 -> (sum, carry)."""
+        a_xor_b = self.xor(a, b)
+        a_and_b = self.and_(a, b)
+        a_xor_b_and_c = self.and_(a_xor_b, c)
+        s = self.xor(a_xor_b, c)
+        carry = self.or_(a_and_b, a_xor_b_and_c)
+        return s, carry
+
+    def add(self, a_bits, b_bits, cin):
+        """examples/add_two_numbers.rs:31-50 -> (sum bits, carry out)."""
+        assert len(a_bits) == len(b_bits), "Cannot add two numbers with different number of bits!"
+        result, carry = [], cin
+        for x, y in zip(a_bits, b_bits):
+            s, carry = self.full_adder(x, y, carry)
+            result.append(s)
+        return result, carry
+
+    # -- schedule ----------------------------------------------------------------------
+    @property
+    def n_wires(self) -> int:
+        return self._n_wires
+
+    def levels(self):
+        """Gates grouped by level (all operands of level L come from levels < L)."""
+        depth = max((g.level for g in self.gates), default=0)
+        out = [[] for _ in range(depth)]
+        for g in self.gates:
+            out[g.level - 1].append(g)
+        return out
+
+    # -- execution -----------------------------------------------------------------------
+    def run_dev(self, eng: E.Engine, inputs, stream=None):
+        """inputs: int32 CUDA tensor [n_inputs][B][n+1]; returns the wire store [n_wires][B][n+1]
+        (int32 CUDA tensor, rows of non-existent wires undefined).  One launch per level."""
+        import torch
+
+        n_in, B, w = inputs.shape
+        assert n_in == self.n_inputs
+        wires = torch.empty((self.n_wires, B, w), dtype=torch.int32, device=inputs.device)
+        wires[:n_in] = inputs
+        for lvl in self.levels():
+            ia = torch.tensor([g.a for g in lvl], device=inputs.device)
+            ib = torch.tensor([g.b for g in lvl], device=inputs.device)
+            io = torch.tensor([g.out for g in lvl], device=inputs.device)
+            codes = torch.tensor([g.op for g in lvl], dtype=torch.uint8, device=inputs.device)
+            a = wires.index_select(0, ia).reshape(-1, w)
+            b = wires.index_select(0, ib).reshape(-1, w)
+            gc = codes.repeat_interleave(B).contiguous()
+            out = torch.empty_like(a)
+            eng.batch_gates_mixed_dev(gc, a, b, out, stream)
+            wires.index_copy_(0, io, out.reshape(len(lvl), B, w))
+        return wires
+
+    def run(self, eng: E.Engine, inputs) -> np.ndarray:
+        """Host convenience: inputs uint32 [n_inputs][B][n+1] -> all wires uint32 [n_wires][B][n+1]."""
+        import torch
+
+        dev = torch.device("cuda", eng.device)
+        t = torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.uint32).view(np.int32)).to(dev)
+        with torch.cuda.device(dev):
+            wires = self.run_dev(eng, t)
+            torch.cuda.synchronize()
+        return wires.cpu().numpy().view(np.uint32)
+
+    def run_reference(self, gate_fn, inputs) -> np.ndarray:
+        """Evaluate gate by gate with `gate_fn(op, a[B][n+1], b[B][n+1]) -> [B][n+1]`: the order
+        the reference's example executes it in (the tests plug their CPU checker in here)."""
+        inputs = np.ascontiguousarray(inputs, dtype=np.uint32)
+        wires = np.zeros((self.n_wires,) + inputs.shape[1:], np.uint32)
+        wires[: self.n_inputs] = inputs
+        for g in self.gates:
+            wires[g.out] = gate_fn(g.op, wires[g.a], wires[g.b])
+        return wires

@@ -135,6 +135,7 @@ struct BlindRotateArgs {
   const uint32_t *in_a;  // [count][n+1]
   const uint32_t *in_b;  // [count][n+1] or nullptr when cb == 0
   uint32_t ca, cb, cconst;
+  const uint8_t *gate_codes;  // optional [count]: per-ciphertext tfhe_hip_gate overriding ca/cb/cconst
   const uint32_t *testvec;  // [2][N] (per_ct_stride == 0) or [count][2][N]
   size_t per_ct_stride;     // in u32 elements: 0 or 2N
   const double2 *bsk;       // engine order
@@ -146,6 +147,13 @@ struct BlindRotateArgs {
   uint32_t *out_lv1;    // [count][N+1]  sample_extract_index(.,0)
   uint32_t *out_ext2;   // [count][n+1]  sample_extract_index_2(.,0)
 };
+
+// src/gates.rs:54-150 as (ca, cb, const): prepared = ca*a + cb*b, prepared.b += const.
+// Index = tfhe_hip_gate; constants are utils::f64_to_torus(+-1/8, +-1/4) (utils.rs:9-12).
+__device__ constexpr uint32_t kGateCa[11] = {0xFFFFFFFFu, 1u, 1u, 1u, 1u, 0xFFFFFFFFu, 0xFFFFFFFFu, 1u, 0xFFFFFFFFu, 1u, 1u};
+__device__ constexpr uint32_t kGateCb[11] = {0xFFFFFFFFu, 1u, 1u, 2u, 0xFFFFFFFEu, 0xFFFFFFFFu, 1u, 0xFFFFFFFFu, 1u, 0xFFFFFFFFu, 0u};
+__device__ constexpr uint32_t kGateCc[11] = {0x20000000u, 0x20000000u, 0xE0000000u, 0x40000000u, 0xC0000000u, 0xE0000000u,
+                                             0xE0000000u, 0xE0000000u, 0x20000000u, 0x20000000u, 0u};
 
 // LDS per workgroup: FFT tile | accumulator (a then b, natural order) | T2 table | rotation amounts
 constexpr int kAccBytes = 2 * kN * 4;
@@ -173,17 +181,24 @@ __global__ __launch_bounds__(64, WPS) void k_blind_rotate(BlindRotateArgs A) {
   tw.load(A.tw, t2tab, lane);
 
   // ---- gate linear prep + rotation amounts ---------------------------------
+  uint32_t gca = A.ca, gcb = A.cb, gcc = A.cconst;
+  if (A.gate_codes) {  // mixed batch: this ciphertext's own gate (same table as the host's gate_prep)
+    const uint32_t code = A.gate_codes[ct] < 11 ? A.gate_codes[ct] : 10u;
+    gca = kGateCa[code];
+    gcb = kGateCb[code];
+    gcc = kGateCc[code];
+  }
   const uint32_t *pa = A.in_a + ct * (size_t)(n + 1);
-  const uint32_t *pb = A.in_b ? A.in_b + ct * (size_t)(n + 1) : nullptr;
+  const uint32_t *pb = (A.in_b && gcb) ? A.in_b + ct * (size_t)(n + 1) : nullptr;
   for (int i = lane; i < n; i += 64) {
-    uint32_t p = A.ca * pa[i];
-    if (pb) p += A.cb * pb[i];
+    uint32_t p = gca * pa[i];
+    if (pb) p += gcb * pb[i];
     // a_tilda = (p +wrap 2^20) >> 21   (trgsw.rs:210-211)
     s_abar[i] = (uint16_t)((uint32_t)(p + (1u << 20)) >> 21);
   }
-  uint32_t pbody = A.ca * pa[n];
-  if (pb) pbody += A.cb * pb[n];
-  pbody += A.cconst;
+  uint32_t pbody = gca * pa[n];
+  if (pb) pbody += gcb * pb[n];
+  pbody += gcc;
   // b_tilda = 2N - ((b as usize + 2^20) >> 21), no 32-bit wrap (trgsw.rs:202-203)
   const int b_tilda = 2 * kN - (int)(((uint64_t)pbody + (1ull << 20)) >> 21);
 

@@ -163,7 +163,8 @@ size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx
 
 int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, const uint32_t *in_b,
                         GatePrep gp, const uint32_t *testvec, int per_ct, size_t count,
-                        uint32_t *out_trlwe, uint32_t *out_lv1, uint32_t *out_ext2) {
+                        uint32_t *out_trlwe, uint32_t *out_lv1, uint32_t *out_ext2,
+                        const uint8_t *gate_codes = nullptr) {
   if (count == 0) return TFHE_HIP_OK;
   if (count > 0x7FFFFFFFull) return fail(ctx, TFHE_HIP_EINVAL, "count too large");
   BlindRotateArgs A;
@@ -172,6 +173,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.ca = gp.ca;
   A.cb = gp.cb;
   A.cconst = gp.cconst;
+  A.gate_codes = gate_codes;
   A.testvec = testvec ? testvec : ctx->d_testvec;
   A.per_ct_stride = (testvec && per_ct) ? (size_t)2 * kN : 0;
   A.bsk = ctx->d_bsk;
@@ -204,6 +206,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     BlindRotateArgs S = A;
     S.in_a = A.in_a + done * (size_t)(ctx->P.n + 1);
     if (A.in_b) S.in_b = A.in_b + done * (size_t)(ctx->P.n + 1);
+    if (A.gate_codes) S.gate_codes = A.gate_codes + done;
     S.testvec = A.testvec + done * A.per_ct_stride;
     if (A.out_trlwe) S.out_trlwe = A.out_trlwe + done * (size_t)(2 * kN);
     if (A.out_lv1) S.out_lv1 = A.out_lv1 + done * (size_t)(kN + 1);
@@ -248,6 +251,14 @@ int gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b, 
   if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
   CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
+  return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
+}
+
+int gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b, uint32_t *out,
+                    size_t count, hipStream_t s) {
+  GatePrep gp{1u, 1u, 0u};  // placeholders; cb != 0 keeps in_b attached, the kernel reads the codes
+  CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+  CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr, gates));
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
 }
 
@@ -468,6 +479,16 @@ int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, cons
   return gate_dev(ctx, gate, a, b, out, count, pick(ctx, stream));
 }
 
+int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                   uint32_t *out, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!gates || !a || !b || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return gates_mixed_dev(ctx, gates, a, b, out, count, pick(ctx, stream));
+}
+
 int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                  int per_ct, int keyswitch, uint32_t *out, size_t count,
                                  void *stream) {
@@ -519,6 +540,26 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
   if (gp.cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
   CHK(ensure(ctx, ctx->h_out, bytes));
   CHK(gate_dev(ctx, gate, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p, (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                               uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!gates || !a || !b || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  for (size_t i = 0; i < count; ++i)
+    if (gates[i] > TFHE_HIP_COPY) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(to_dev(ctx, ctx->h_idx, gates, count));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(gates_mixed_dev(ctx, (const uint8_t *)ctx->h_idx.p, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p,
+                      (uint32_t *)ctx->h_out.p, count, ctx->stream));
   return to_host(ctx, out, ctx->h_out, bytes);
 }
 

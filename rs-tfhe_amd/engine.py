@@ -114,6 +114,16 @@ class Engine:
         self._chk(self._lib.tfhe_hip_batch_gate(self._ctx, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
         return out
 
+    def batch_gates_mixed(self, gates, a, b) -> np.ndarray:
+        """Per-ciphertext gate selectors (one launch for a whole circuit level)."""
+        a, b = self._cts(a), self._cts(b)
+        g = np.ascontiguousarray(gates, dtype=np.uint8).reshape(-1)
+        if len(g) != len(a) or b.shape != a.shape:
+            raise ValueError("gates / operand batches differ in length")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_gates_mixed(self._ctx, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
+        return out
+
     def batch_bootstrap(self, cts, testvec=None, keyswitch: bool = True) -> np.ndarray:
         cts = self._cts(cts)
         out = np.empty_like(cts)
@@ -187,12 +197,24 @@ class Engine:
             import torch
 
             stream = torch.cuda.current_stream()
-        return C.c_void_p(stream.cuda_stream)
+        # torch's default stream is the legacy null stream (handle 0); the C ABI reads NULL as "the
+        # context's own stream", so name the null stream explicitly: hipStreamLegacy == (hipStream_t)1
+        return C.c_void_p(stream.cuda_stream or 1)
 
     def batch_gate_dev(self, gate: int, a, b, out, stream=None) -> None:
         count = a.shape[0]
         self._chk(
             self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream))
+        )
+
+    def batch_gates_mixed_dev(self, gates, a, b, out, stream=None) -> None:
+        """gates: uint8 CUDA tensor [count]; a, b, out: int32 CUDA tensors [count][n+1]."""
+        if not gates.is_cuda or gates.element_size() != 1 or not gates.is_contiguous():
+            raise ValueError("gates must be a contiguous uint8 CUDA tensor")
+        self._chk(
+            self._lib.tfhe_hip_batch_gates_mixed_dev(
+                self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), a.shape[0], self._stream_ptr(stream)
+            )
         )
 
     def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:

@@ -275,6 +275,58 @@ def test_xor_and_mux_80bit(O, keys80):
     assert np.array_equal(eng.batch_mux(ca, cb, cc, naive=False), O.batch_mux(ck, ca, cb, cc, naive=False))
 
 
+# ---- mixed-gate batches and levelised circuits ---------------------------------------------
+def test_mixed_gate_batch(O, eng128, keys128):
+    """Per-ciphertext gate selectors: one launch, ten different gates."""
+    sk, ck = keys128
+    rng = np.random.default_rng(30)
+    gates = np.array(list(range(10)) * 3 + [O.GATE_COPY, O.GATE_NAND], np.uint8)
+    A = rng.integers(0, 2, len(gates)).astype(bool)
+    B = rng.integers(0, 2, len(gates)).astype(bool)
+    ca, cb = sk.encrypt_bool(A, 700), sk.encrypt_bool(B, 701)
+    got = eng128.batch_gates_mixed(gates, ca, cb)
+    for i, g in enumerate(gates):
+        exp = O.batch_gate(ck, int(g), ca[i], cb[i] if g != O.GATE_COPY else None)[0]
+        assert np.array_equal(got[i], exp), f"gate {g} at {i}"
+    from rs_tfhe_amd import _capi
+
+    with pytest.raises(_capi.TfheHipError):
+        eng128.batch_gates_mixed(np.array([77], np.uint8), ca[:1], cb[:1])
+
+
+def test_ripple_carry_adder_circuit(O, eng128, keys128):
+    """examples/add_two_numbers.rs: 4-bit add of 6 independent input pairs, levelised on the GPU,
+    vs the same DAG evaluated gate by gate on the CPU oracle (bit-exact) and vs plain integers."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    nbits, B = 4, 6
+    rng = np.random.default_rng(31)
+    xs, ys = rng.integers(0, 16, B), rng.integers(0, 16, B)
+    c = R.Circuit(2 * nbits + 1)
+    a_w, b_w, cin = list(range(nbits)), list(range(nbits, 2 * nbits)), 2 * nbits
+    sum_w, carry_w = c.add(a_w, b_w, cin)
+    assert len(c.gates) == 5 * nbits and len(c.levels()) == 2 * nbits + 1  # carry chain: 2 levels per bit
+    bits = np.zeros((2 * nbits + 1, B), bool)
+    for i in range(nbits):
+        bits[i] = (xs >> i) & 1
+        bits[nbits + i] = (ys >> i) & 1
+    inputs = np.stack([sk.encrypt_bool(bits[w], 800 + w) for w in range(2 * nbits + 1)])
+    wires = c.run(eng128, inputs)
+    ref = c.run_reference(lambda op, a, b: O.batch_gate(ck, op, a, b), inputs)
+    assert np.array_equal(wires, ref)
+    total = np.zeros(B, np.int64)
+    for i, w in enumerate(sum_w):
+        total += sk.decrypt_bool(wires[w]).astype(np.int64) << i
+    total += sk.decrypt_bool(wires[carry_w]).astype(np.int64) << nbits
+    assert np.array_equal(total, xs + ys)
+    # mux_naive as a circuit == the batched mux_naive entry point
+    m = R.Circuit(3)
+    out_w = m.mux_naive(0, 1, 2)
+    trip = np.stack([sk.encrypt_bool(rng.integers(0, 2, 5).astype(bool), 900 + k) for k in range(3)])
+    assert np.array_equal(m.run(eng128, trip)[out_w], eng128.batch_mux(trip[0], trip[1], trip[2], naive=True))
+
+
 # ---- golden fixture (no oracle involved) -----------------------------------------------------
 def test_golden_toy_instance(golden):
     import rs_tfhe_amd as R
