@@ -275,6 +275,28 @@ def test_xor_and_mux_80bit(O, keys80):
     assert np.array_equal(eng.batch_mux(ca, cb, cc, naive=False), O.batch_mux(ck, ca, cb, cc, naive=False))
 
 
+def test_other_parameter_sets_bit_exact(O):
+    """SECURITY_UINT1 (l=2, bgbit=10: the general rounding path, L=2 kernels) and SECURITY_110_BIT
+    (t=8): whole bootstraps bit-identical to the CPU path, gates decrypt correctly."""
+    import rs_tfhe_amd as R
+
+    for op_params, seed in ((O.SECURITY_UINT1, 41), (O.SECURITY_110_BIT, 42)):
+        sk, ck = oracle_keys(O, op_params, seed=seed)
+        pk = _cloud_key(ck)
+        eng = R.bootstrap.engine_for(pk.params, 0)
+        eng.ensure_key(pk)
+        A = np.array([1, 1, 0, 0, 1, 0, 1], bool)
+        B = np.array([1, 0, 1, 0, 0, 0, 1], bool)
+        ca, cb = sk.encrypt_bool(A, seed + 100), sk.encrypt_bool(B, seed + 200)
+        for op in (O.GATE_NAND, O.GATE_XOR, O.GATE_ORYN):
+            got = eng.batch_gate(op, ca, cb)
+            assert np.array_equal(got, O.batch_gate(ck, op, ca, cb)), (op_params.name, op)
+            exp = np.array([O.GATE_TRUTH[op](bool(a), bool(b)) for a, b in zip(A, B)])
+            assert np.array_equal(sk.decrypt_bool(got), exp)
+        tr = eng.batch_blind_rotate(ca[:3])
+        assert np.array_equal(tr, O.batch_blind_rotate(ck, ca[:3]))
+
+
 # ---- mixed-gate batches and levelised circuits ---------------------------------------------
 def test_mixed_gate_batch(O, eng128, keys128):
     """Per-ciphertext gate selectors: one launch, ten different gates."""
