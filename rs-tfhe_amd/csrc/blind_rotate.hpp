@@ -166,8 +166,8 @@ constexpr int kStageLdsBytes = kTileBytes + kT2Bytes;  // stage kernels: tile | 
 // chain.  X^k * acc is then just an indexed re-read of that array (poly_mul_with_x_k
 // never materialises), and the 32 VGPRs an in-register accumulator would pin across
 // the eight FFTs are free, which is what lets two waves share a SIMD (<= 256 VGPRs).
-template <int L, bool FAST, int WPS>
-__global__ __launch_bounds__(64, WPS) void k_blind_rotate(BlindRotateArgs A) {
+template <int L, bool FAST>
+__global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
   uint32_t *acc = reinterpret_cast<uint32_t *>(smem + kTileBytes);

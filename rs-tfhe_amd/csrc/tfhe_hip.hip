@@ -51,8 +51,6 @@ struct tfhe_hip_ctx {
   bool profiling = false;
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
-  int br_wps = 2;  // blind-rotate waves per SIMD the kernel is compiled for (register budget 512 / wps)
-  size_t br_lds_pad = 0;  // experiment knob: extra LDS per workgroup to lower residency
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
@@ -139,12 +137,9 @@ typedef void (*br_kernel_t)(BlindRotateArgs);
 br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
   switch (ctx->P.l) {
-    case 1: return ctx->br_wps == 2 ? (f ? k_blind_rotate<1, true, 2> : k_blind_rotate<1, false, 2>)
-                                    : (f ? k_blind_rotate<1, true, 1> : k_blind_rotate<1, false, 1>);
-    case 2: return ctx->br_wps == 2 ? (f ? k_blind_rotate<2, true, 2> : k_blind_rotate<2, false, 2>)
-                                    : (f ? k_blind_rotate<2, true, 1> : k_blind_rotate<2, false, 1>);
-    default: return ctx->br_wps == 2 ? (f ? k_blind_rotate<3, true, 2> : k_blind_rotate<3, false, 2>)
-                                     : (f ? k_blind_rotate<3, true, 1> : k_blind_rotate<3, false, 1>);
+    case 1: return f ? k_blind_rotate<1, true> : k_blind_rotate<1, false>;
+    case 2: return f ? k_blind_rotate<2, true> : k_blind_rotate<2, false>;
+    default: return f ? k_blind_rotate<3, true> : k_blind_rotate<3, false>;
   }
 }
 
@@ -159,7 +154,7 @@ ep_kernel_t ep_kernel(const tfhe_hip_ctx *ctx) {
   }
 }
 
-size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx->P.n) + ctx->br_lds_pad; }
+size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx->P.n); }
 
 int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, const uint32_t *in_b,
                         GatePrep gp, const uint32_t *testvec, int per_ct, size_t count,
@@ -382,8 +377,6 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
-  if (const char *env = getenv("TFHE_HIP_BR_LDS_PAD")) ctx->br_lds_pad = (size_t)atol(env) & ~(size_t)15;
-  if (const char *env = getenv("TFHE_HIP_BR_WPS")) ctx->br_wps = atoi(env) == 1 ? 1 : 2;
   std::vector<double2> tw;
   make_twiddles(tw);
   if ((e = hipMalloc((void **)&ctx->d_tw, tw.size() * sizeof(double2))) != hipSuccess)
