@@ -111,6 +111,21 @@ const char *tfhe_hip_name(void);
 int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
                             uint32_t decomp_offset, const uint32_t *testvec);
 
+/* Replaces: CloudKey::new(&secret_key) (src/key.rs:59-66) = gen_decomposition_offset (:78-89),
+ * gen_testvec (:91-100), gen_key_switching_key (:102-122) and gen_bootstrapping_key (:124-156),
+ * generated on the GPU straight into the context (no upload).  Needs the secret key, so it is a
+ * client-side call.  key_lv0 [n], key_lv1 [N]: 0/1 words (src/key.rs:21-49).
+ * alpha_ksk = tlwe_lv0.alpha (KSK_ALPHA, params.rs:468), alpha_bsk = tlwe_lv1.alpha (BSK_ALPHA,
+ * :469).  The reference draws from an unseeded thread_rng; here `seed` fixes the key bit-for-bit
+ * (counter-based Philox4x32-10), the distributions are the reference's. */
+int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                           double alpha_ksk, double alpha_bsk, uint64_t seed);
+
+/* The loaded / generated cloud key back in the reference layouts of tfhe_hip_load_cloud_key
+ * (any pointer may be NULL to skip that field).  load -> export is the identity. */
+int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
+                              uint32_t *testvec);
+
 /* ---- the hot path, batched --------------------------------------------- */
 
 /* Replaces: gates::batch_{nand,and,or,xor,nor,xnor}[_with_railgun]

@@ -49,6 +49,8 @@ SIGNATURES = {
     "tfhe_hip_last_error": (C.c_char_p, [_CTX]),
     "tfhe_hip_name": (C.c_char_p, []),
     "tfhe_hip_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
+    "tfhe_hip_gen_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, C.c_uint64]),
+    "tfhe_hip_export_cloud_key": (C.c_int, [_CTX, _P, _P, C.POINTER(C.c_uint32), _P]),
     "tfhe_hip_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_gates_mixed": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),

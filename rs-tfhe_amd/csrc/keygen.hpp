@@ -1,0 +1,252 @@
+// keygen.hpp -- cloud-key generation on the GPU.
+//
+// Replaces CloudKey::new(&secret_key) (src/key.rs:59-66) for callers that hold the secret key
+// on the host: gen_key_switching_key (key.rs:102-122, the reference's slowest step: a sequential
+// loop of N*t*(base-1) TLWE encryptions) and gen_bootstrapping_key (key.rs:124-156: n TRGSW
+// encryptions = n*2l TRLWE zero-encryptions, each with one negacyclic product a (*) s1, then 4l
+// forward FFTs).  The keys are written straight into the engine layouts, so the 172 MB upload
+// and the two conversion kernels disappear.
+//
+// Randomness: the reference draws from an unseeded thread_rng (tlwe.rs:38, trlwe.rs:36-41); here a
+// counter-based Philox4x32-10 stream keyed by (seed, row) gives every word a fixed position, so a
+// seed reproduces a key bit-for-bit on any launch geometry.  Distributions are the reference's:
+// uniform u32 mask, N(0, alpha) noise added on the torus via f64_to_torus (utils.rs:9-38).
+#pragma once
+#include "blind_rotate.hpp"
+#include "key_switch.hpp"
+
+namespace tfhe {
+
+// ---- Philox4x32-10 ------------------------------------------------------------------
+struct Philox {
+  uint32_t k0, k1;
+  __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t a, uint32_t b) const {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ a;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ b;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+  }
+  // 4 words for counter (c0, c1, c2, c3)
+  __device__ __forceinline__ void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
+    uint32_t c[4] = {c0, c1, c2, c3};
+    uint32_t a = k0, b = k1;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+      round(c, a, b);
+      a += 0x9E3779B9u;
+      b += 0xBB67AE85u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+  }
+};
+
+// src/utils.rs:9-12
+__device__ __forceinline__ uint32_t dev_f64_to_torus(double d) {
+  double t = fmod(d, 1.0) * 4294967296.0;
+  return (uint32_t)(long long)t;
+}
+
+// two N(0, sigma) samples from four uniform words (Box-Muller)
+__device__ __forceinline__ void gauss2(const uint32_t (&w)[4], double sigma, double &g0, double &g1) {
+  const double u1 = ((double)(((uint64_t)w[0] << 21) ^ (w[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);  // (0,1]
+  const double u2 = (double)(((uint64_t)w[2] << 21) ^ (w[3] >> 11)) * (1.0 / 9007199254740992.0);          // [0,1)
+  const double rad = sqrt(-2.0 * log(u1)) * sigma;
+  double s, c;
+  sincospi(2.0 * u2, &s, &c);
+  g0 = rad * c;
+  g1 = rad * s;
+}
+
+// utils.rs:22-38 gaussian_f64(mu): f64_to_torus(sample) + f64_to_torus(mu)
+__device__ __forceinline__ uint32_t gaussian_torus(double mu, double g) { return dev_f64_to_torus(g) + dev_f64_to_torus(mu); }
+
+// ---- key-switching key: key.rs:102-122, rows written in the engine layout -------------
+// One workgroup per row (i, j, k); row = TLWELv0::encrypt_f64(k*s1[i] / 2^((j+1)*basebit), alpha, s0)
+// (tlwe.rs:37-53): a uniform, b = <a, s0> + gaussian_f64(p).
+__global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ key_lv0, const uint32_t *__restrict__ key_lv1,
+                                                  uint32_t *__restrict__ ksk_eng, int n, int basebit, int t,
+                                                  double alpha, uint32_t seed_lo, uint32_t seed_hi) {
+  __shared__ uint32_t s_part[4];
+  const uint32_t row = blockIdx.x;  // base*t*i + base*j + k
+  const int base = 1 << basebit;
+  const int k = row % base, j = (row / base) % t, i = row / (base * t);
+  const int rw = ksk_row_words(n);
+  uint32_t *dst = ksk_eng + (size_t)row * rw;
+  const int tid = threadIdx.x;
+  if (k == 0) {  // unused slots (key.rs:109-111)
+    for (int x = tid; x < rw; x += 256) dst[x] = 0u;
+    return;
+  }
+  const Philox ph{seed_lo, seed_hi ^ 0x4B53u};
+  uint32_t inner = 0;
+  for (int x4 = tid; x4 * 4 < n; x4 += 256) {
+    uint32_t w[4];
+    ph.gen((uint32_t)x4, row, 0u, 0u, w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int x = x4 * 4 + c;
+      if (x < n) {
+        dst[x] = w[c];
+        inner += key_lv0[x] * w[c];
+      }
+    }
+  }
+  // block reduction of the wrapping inner product
+  for (int off = 32; off > 0; off >>= 1) inner += __shfl_down(inner, off);
+  if ((tid & 63) == 0) s_part[tid >> 6] = inner;
+  __syncthreads();
+  if (tid == 0) {
+    const uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    uint32_t w[4];
+    ph.gen(0xFFFFFFFFu, row, 1u, 0u, w);
+    double g0, g1;
+    gauss2(w, alpha, g0, g1);
+    const double p = (double)((uint32_t)k * key_lv1[i]) / (double)(1u << ((j + 1) * basebit));  // key.rs:113-114
+    dst[n] = total + gaussian_torus(p, g0);
+    for (int x = n + 1; x < rw; ++x) dst[x] = 0u;
+  }
+}
+
+// ---- bootstrapping key: key.rs:124-156 ------------------------------------------------
+// One wave per TRLWE row (i, r) of TRGSW(s0[i]) (trgsw.rs:29-49):
+//   a uniform, b = gaussian(0) + a (*) s1        (trlwe.rs:30-52, product via the FFT as poly_mul does)
+//   r <  l: a[0] += s0[i] * f64_to_torus(Bg^-(r+1));  r >= l: b[0] += ... (trgsw.rs:44-47)
+//   spectrum of a and b (TRGSWLv1FFT::new, trgsw.rs:58-68) written in engine order, scaled 2^-10.
+// s1_spec: forward spectrum of the level-1 key in the forward-FFT bin order (k_key_spectrum).
+__global__ __launch_bounds__(64) void k_key_spectrum(const uint32_t *__restrict__ key_lv1, const double2 *__restrict__ twt,
+                                                      double2 *__restrict__ s1_spec) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2 *tile = reinterpret_cast<double2 *>(smem);
+  const int lane = threadIdx.x;
+  Twiddles tw;
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
+  double re[8], im[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    re[m] = (double)(int32_t)key_lv1[lane + 64 * m];
+    im[m] = (double)(int32_t)key_lv1[lane + 64 * m + kN2];
+  }
+  fft_forward(re, im, tw, tile, lane);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) s1_spec[s * 64 + lane] = make_double2(re[s], im[s]);
+}
+
+template <int L>
+__global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key_lv0, const double2 *__restrict__ s1_spec,
+                                                 const double2 *__restrict__ twt, double2 *__restrict__ bsk_eng,
+                                                 int bgbit, double alpha, uint32_t seed_lo, uint32_t seed_hi) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double2 *tile = reinterpret_cast<double2 *>(smem);
+  const int lane = threadIdx.x;
+  const uint32_t row = blockIdx.x;  // i * 2L + r
+  const int r = row % (2 * L), i = row / (2 * L);
+  Twiddles tw;
+  tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
+  const Philox ph{seed_lo, seed_hi ^ 0x4253u};
+
+  // a: uniform; e: gaussian.  Lane l owns coefficients l+64m (lo) and l+64m+512 (hi), m < 8:
+  // 16 words of each per lane = 4 Philox blocks for a, 8 for the Gaussian pairs.
+  uint32_t a_lo[8], a_hi[8], b_lo[8], b_hi[8];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t w[4];
+    ph.gen((uint32_t)(lane * 4 + q), row, 2u, 0u, w);
+    a_lo[2 * q] = w[0];
+    a_lo[2 * q + 1] = w[1];
+    a_hi[2 * q] = w[2];
+    a_hi[2 * q + 1] = w[3];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    uint32_t w[4];
+    ph.gen((uint32_t)(lane * 8 + q), row, 3u, 0u, w);
+    double g0, g1;
+    gauss2(w, alpha, g0, g1);
+    b_lo[q] = gaussian_torus(0.0, g0);
+    b_hi[q] = gaussian_torus(0.0, g1);
+  }
+  // poly_res = a (*) s1 (klemsa.rs:152-174): A*S/512 through the inverse
+  double re[8], im[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    re[m] = (double)(int32_t)a_lo[m];
+    im[m] = (double)(int32_t)a_hi[m];
+  }
+  fft_forward(re, im, tw, tile, lane);
+  double are[8], aim[8];  // keep A for the key spectrum of `a` (linear: gadget added below)
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    are[s] = re[s];
+    aim[s] = im[s];
+    const double2 sp = s1_spec[s * 64 + lane];
+    const double pr = (re[s] * sp.x - im[s] * sp.y) * 0x1p-9;
+    const double pi = (re[s] * sp.y + im[s] * sp.x) * 0x1p-9;
+    re[s] = pr;
+    im[s] = pi;
+  }
+  fft_inverse(re, im, tw, tile, lane);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    b_lo[m] += round_to_torus<false>(re[m]);
+    b_hi[m] += round_to_torus<false>(im[m]);
+  }
+  // gadget: p * f64_to_torus(Bg^-(d+1)) on coefficient 0 of a (rows < L) or b (rows >= L)
+  const uint32_t p = key_lv0[i];
+  const int d = r % L;
+  const uint32_t gadget = p * dev_f64_to_torus(exp2(-(double)(bgbit * (d + 1))));
+  // spectrum of a: FFT is linear and the gadget sits on coefficient 0 = lane 0, slot 0, real part;
+  // redo the forward transform only when it changed (r < L) -- cheaper to just transform again.
+  if (r < L) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      re[m] = (double)(int32_t)(a_lo[m] + ((lane == 0 && m == 0) ? gadget : 0u));
+      im[m] = (double)(int32_t)a_hi[m];
+    }
+    fft_forward(re, im, tw, tile, lane);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      are[s] = re[s];
+      aim[s] = im[s];
+    }
+  } else if (lane == 0) {
+    b_lo[0] += gadget;
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    re[m] = (double)(int32_t)b_lo[m];
+    im[m] = (double)(int32_t)b_hi[m];
+  }
+  fft_forward(re, im, tw, tile, lane);
+  double2 *dst = bsk_eng + (size_t)row * 2 * kN2;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    // reference stores 2*DFT (klemsa.rs:112-113); engine folds 2^-10 on top: 2 * 2^-10 = 2^-9
+    dst[s * 64 + lane] = make_double2(are[s] * 0x1p-9, aim[s] * 0x1p-9);
+    dst[kN2 + s * 64 + lane] = make_double2(re[s] * 0x1p-9, im[s] * 0x1p-9);
+  }
+}
+
+// ---- export: engine layouts back to the reference layouts (tests, key persistence) -------
+__global__ void k_bsk_export(const double2 *__restrict__ eng, double *__restrict__ ref, size_t polys) {
+  size_t p = blockIdx.x;
+  int t = threadIdx.x;  // engine position s*64 + mu
+  int s = t >> 6, mu = t & 63;
+  int k = bin_of(mu, s);
+  double2 v = eng[p * kN2 + t];
+  ref[p * kN + k] = v.x * 0x1p10;
+  ref[p * kN + k + kN2] = v.y * 0x1p10;
+}
+
+__global__ void k_ksk_export(const uint32_t *__restrict__ eng, uint32_t *__restrict__ ref, int n, size_t rows) {
+  const size_t r = blockIdx.x;
+  if (r >= rows) return;
+  const int rw = ksk_row_words(n);
+  for (int x = threadIdx.x; x <= n; x += blockDim.x) ref[r * (size_t)(n + 1) + x] = eng[r * (size_t)rw + x];
+}
+
+}  // namespace tfhe

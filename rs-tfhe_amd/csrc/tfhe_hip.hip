@@ -19,6 +19,7 @@
 #include "../../include/tfhe_hip.h"
 #include "blind_rotate.hpp"
 #include "key_switch.hpp"
+#include "keygen.hpp"
 
 using namespace tfhe;
 
@@ -457,6 +458,81 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->offset = decomp_offset;
   ctx->key_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
+                           double alpha_bsk, uint64_t seed) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (!key_lv0 || !key_lv1) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
+  if (!(alpha_ksk >= 0.0) || !(alpha_bsk >= 0.0)) return fail(ctx, TFHE_HIP_EINVAL, "negative noise parameter");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const tfhe_hip_params &P = ctx->P;
+  const int base = 1 << P.basebit;
+  const size_t polys = (size_t)P.n * 2 * P.l * 2;
+  ctx->key_loaded = false;
+  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, polys * kN * sizeof(double)));
+  if (!ctx->d_ksk)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4));
+  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
+  CHK(to_dev(ctx, ctx->h_a, key_lv0, (size_t)P.n * 4));
+  CHK(to_dev(ctx, ctx->h_b, key_lv1, (size_t)kN * 4));
+  CHK(ensure(ctx, ctx->h_c, (size_t)kN2 * sizeof(double2)));
+  const uint32_t *d_k0 = (const uint32_t *)ctx->h_a.p, *d_k1 = (const uint32_t *)ctx->h_b.p;
+  double2 *d_spec = (double2 *)ctx->h_c.p;
+  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(k_key_spectrum, dim3(1), dim3(64), kStageLdsBytes, ctx->stream, d_k1, ctx->d_tw, d_spec);
+  HIPCHK(ctx, hipGetLastError());
+  const dim3 bgrid((unsigned)(P.n * 2 * P.l));
+  switch (P.l) {
+    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
+    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
+    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
+  }
+  HIPCHK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(k_gen_ksk, dim3((unsigned)((size_t)kN * P.t * base)), dim3(256), 0, ctx->stream, d_k0, d_k1,
+                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, slo, shi);
+  HIPCHK(ctx, hipGetLastError());
+  // decomposition offset (key.rs:78-89) and test vector (key.rs:91-100)
+  uint32_t off = 0;
+  for (int i = 0; i < P.l; ++i) off += ((1u << P.bgbit) / 2) * (1u << (32 - (i + 1) * P.bgbit));
+  std::vector<uint32_t> tv(2 * kN, 0u);
+  for (int i = 0; i < kN; ++i) tv[kN + i] = 0x20000000u;  // f64_to_torus(0.125)
+  HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, tv.data(), 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->offset = off;
+  ctx->key_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
+                              uint32_t *testvec) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const tfhe_hip_params &P = ctx->P;
+  const int base = 1 << P.basebit;
+  if (bsk) {
+    const size_t polys = (size_t)P.n * 2 * P.l * 2;
+    CHK(ensure(ctx, ctx->h_out, polys * kN * sizeof(double)));
+    hipLaunchKernelGGL(k_bsk_export, dim3((unsigned)polys), dim3(512), 0, ctx->stream, ctx->d_bsk, (double *)ctx->h_out.p, polys);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(to_host(ctx, bsk, ctx->h_out, polys * kN * sizeof(double)));
+  }
+  if (ksk) {
+    const size_t rows = (size_t)kN * P.t * base;
+    CHK(ensure(ctx, ctx->h_out, rows * (size_t)(P.n + 1) * 4));
+    hipLaunchKernelGGL(k_ksk_export, dim3((unsigned)rows), dim3(256), 0, ctx->stream, ctx->d_ksk, (uint32_t *)ctx->h_out.p, P.n, rows);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(to_host(ctx, ksk, ctx->h_out, rows * (size_t)(P.n + 1) * 4));
+  }
+  if (decomp_offset) *decomp_offset = ctx->offset;
+  if (testvec) {
+    HIPCHK(ctx, hipMemcpyAsync(testvec, ctx->d_testvec, 2 * kN * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return TFHE_HIP_OK;
 }
 

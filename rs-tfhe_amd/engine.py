@@ -96,6 +96,34 @@ class Engine:
         )
         self._key_id = id(cloud_key)
 
+    def gen_cloud_key(self, key_lv0, key_lv1, seed: int, alpha_ksk=None, alpha_bsk=None) -> None:
+        """CloudKey::new(&secret_key) (src/key.rs:59-66) on the GPU, straight into this context."""
+        p = self.params
+        k0, k1 = _u32(key_lv0).reshape(-1), _u32(key_lv1).reshape(-1)
+        if len(k0) != p.n or len(k1) != N:
+            raise ValueError("secret key has the wrong size for these parameters")
+        self._chk(
+            self._lib.tfhe_hip_gen_cloud_key(
+                self._ctx, _ptr(k0), _ptr(k1),
+                C.c_double(p.alpha_lv0 if alpha_ksk is None else alpha_ksk),
+                C.c_double(p.alpha_lv1 if alpha_bsk is None else alpha_bsk),
+                C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
+            )
+        )
+        self._key_id = ("generated", seed)
+
+    def export_cloud_key(self):
+        """The context's key back as a CloudKey in the reference layouts."""
+        from .key import CloudKey
+
+        p = self.params
+        bsk = np.empty((p.n, 2 * p.l, 2, N), np.float64)
+        ksk = np.empty((N, p.iks_t, p.base, p.n + 1), np.uint32)
+        tv = np.empty((2, N), np.uint32)
+        off = C.c_uint32(0)
+        self._chk(self._lib.tfhe_hip_export_cloud_key(self._ctx, _ptr(bsk), _ptr(ksk), C.byref(off), _ptr(tv)))
+        return CloudKey(p, bsk, ksk, int(off.value), tv)
+
     def ensure_key(self, cloud_key) -> None:
         if self._key_id != id(cloud_key):
             self.load_cloud_key(cloud_key)

@@ -349,6 +349,90 @@ def test_ripple_carry_adder_circuit(O, eng128, keys128):
     assert np.array_equal(m.run(eng128, trip)[out_w], eng128.batch_mux(trip[0], trip[1], trip[2], naive=True))
 
 
+# ---- cloud key: export round trip, generation on the GPU ---------------------------------------
+def test_cloud_key_export_is_identity(O, eng128, keys128):
+    """load -> export reproduces the uploaded key bit-for-bit (the engine-order permutation and
+    the 2^-10 pre-scale are exact; k=0 key-switch rows are zero on both sides)."""
+    sk, ck = keys128
+    out = eng128.export_cloud_key()
+    assert np.array_equal(out.bootstrapping_key, ck.bootstrapping_key)
+    assert np.array_equal(out.key_switching_key, ck.key_switching_key)
+    assert out.decomposition_offset == ck.decomposition_offset
+    assert np.array_equal(out.blind_rotate_testvec, ck.blind_rotate_testvec)
+
+
+def test_gpu_key_generation(O, keys128):
+    """CloudKey::new on the GPU (key.rs:59-66).  RNG streams differ from the host generator, so the
+    bar is structural + functional: every sampled BSK row is a TRLWE encryption of the right gadget
+    value under s1, every sampled KSK row a TLWE encryption of k*s1[i]/base^(j+1) under s0, noise at
+    the requested alpha; gates evaluated with the generated key decrypt correctly; the seed fixes the key."""
+    import rs_tfhe_amd as R
+
+    sk, _ = keys128
+    P = R.params.SECURITY_128_BIT
+    eng = R.Engine(P, 0)
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+    gk = eng.export_cloud_key()
+    assert gk.decomposition_offset == 0x82080000
+    assert not gk.blind_rotate_testvec[0].any() and (gk.blind_rotate_testvec[1] == 0x20000000).all()
+    # BSK rows: spectrum -> torus polys (oracle inverse FFT) -> phase = b - a (*) s1
+    for i in (0, 1, 350, 699):
+        for r in range(2 * P.l):
+            a = O.klemsa_fft(gk.bootstrapping_key[i, r, 0])
+            b = O.klemsa_fft(gk.bootstrapping_key[i, r, 1])
+            want_a = np.zeros(N, np.uint32)
+            want_b = np.zeros(N, np.uint32)
+            g = np.uint32(int(sk.key_lv0[i]) * (1 << (32 - P.bgbit * (r % P.l + 1))))
+            # gadget sits on a[0] for r < l, on b[0] for r >= l (trgsw.rs:44-47); the TRLWE part encrypts 0:
+            # b - a (*) s1 == noise (+ gadget if r >= l), with the a-gadget contributing -g*s1 to the phase
+            phase = (b - O.negacyclic_schoolbook(a, sk.key_lv1)).astype(np.uint32)
+            if r < P.l:
+                phase = (phase + O.negacyclic_schoolbook(np.concatenate([[g], np.zeros(N - 1, np.uint32)]).astype(np.uint32), sk.key_lv1)).astype(np.uint32)
+            else:
+                phase[0] -= g
+            noise = phase.view(np.int32).astype(np.float64) / 2.0**32
+            assert np.abs(noise).max() < 8 * P.alpha_lv1 + 2.0**-31, (i, r, np.abs(noise).max())
+            assert noise.std() > 0.3 * P.alpha_lv1  # it is noise, not zeros
+    # KSK rows
+    s0 = sk.key_lv0.astype(np.uint32)
+    for (i, j, k) in ((0, 0, 1), (5, 3, 2), (1023, 8, 3), (512, 4, 1)):
+        row = gk.key_switching_key[i, j, k]
+        ph = np.uint32(row[P.n] - (row[:P.n] * s0).sum(dtype=np.uint32))
+        want = O.f64_to_torus(float(k * int(sk.key_lv1[i])) / float(1 << ((j + 1) * P.basebit)))
+        err = np.int32(np.uint32(ph - np.uint32(want))) / 2.0**32
+        assert abs(err) < 8 * P.alpha_lv0, (i, j, k, err)
+        assert not gk.key_switching_key[i, j, 0].any()
+    masks = gk.key_switching_key[3, 2, 1, :P.n].astype(np.float64)
+    assert 0.4 < masks.mean() / 2.0**32 < 0.6  # uniform mask words
+    # functional: gates with the generated key
+    A = np.array([1, 1, 0, 0, 1, 0], bool)
+    B = np.array([1, 0, 1, 0, 1, 1], bool)
+    ca, cb = sk.encrypt_bool(A, 77), sk.encrypt_bool(B, 78)
+    for op in (O.GATE_NAND, O.GATE_XOR, O.GATE_AND):
+        got = eng.batch_gate(op, ca, cb)
+        assert np.array_equal(sk.decrypt_bool(got), np.array([O.GATE_TRUTH[op](bool(a), bool(b)) for a, b in zip(A, B)]))
+    # the generated key is an ordinary key: the CPU path with it gives the same ciphertexts
+    class _K:
+        pass
+    ock = O.CloudKey.__new__(O.CloudKey)
+    ock.params = O.SECURITY_128_BIT
+    ock.decomposition_offset = gk.decomposition_offset
+    ock.blind_rotate_testvec = gk.blind_rotate_testvec
+    ock.bootstrapping_key = gk.bootstrapping_key
+    ock.bootstrapping_key_time = None
+    ock.key_switching_key = gk.key_switching_key
+    assert np.array_equal(eng.batch_gate(O.GATE_NAND, ca, cb), O.batch_gate(ock, O.GATE_NAND, ca, cb))
+    # determinism in the seed
+    eng2 = R.Engine(P, 0)
+    eng2.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+    g2 = eng2.export_cloud_key()
+    assert np.array_equal(g2.bootstrapping_key, gk.bootstrapping_key) and np.array_equal(g2.key_switching_key, gk.key_switching_key)
+    eng2.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2026)
+    assert not np.array_equal(eng2.export_cloud_key().key_switching_key, gk.key_switching_key)
+    eng.close()
+    eng2.close()
+
+
 # ---- golden fixture (no oracle involved) -----------------------------------------------------
 def test_golden_toy_instance(golden):
     import rs_tfhe_amd as R
