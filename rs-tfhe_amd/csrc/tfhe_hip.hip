@@ -52,6 +52,7 @@ struct tfhe_hip_ctx {
   bool profiling = false;
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
+  bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
@@ -225,8 +226,14 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
   CHK(record_begin(ctx, s, ctx->ev_ks));
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
-  hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->d_ksk, (uint32_t)ksk_bytes, n,
-                     ctx->P.basebit, ctx->P.t, out, count);
+  const size_t b4_lds = ks_b4_lds_bytes(n, kKsG);
+  const bool b4_fits = (ks_b4_slot_bytes(n) >> 10) <= (uint32_t)(kKsChunksPerWave * (bd >> 6)) && b4_lds <= 64 * 1024;
+  if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
+    hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+                       ctx->P.t, out, count);
+  else
+    hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->d_ksk, (uint32_t)ksk_bytes,
+                       n, ctx->P.basebit, ctx->P.t, out, count);
   HIPCHK(ctx, hipGetLastError());
   CHK(record_end(ctx, s, ctx->ev_ks));
   return TFHE_HIP_OK;
@@ -377,6 +384,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   // pre-rounding magnitude bound: 2l polynomials x N terms x (Bg/2) digit x 2^31 key coefficient
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
   std::vector<double2> tw;
   make_twiddles(tw);
@@ -427,7 +435,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   ctx->key_loaded = false;
   if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bsk_bytes));
   if (!ctx->d_ksk)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
   if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
   // bootstrapping key: upload the reference layout, permute + scale on the device
   double *d_ref = nullptr;
@@ -474,7 +482,7 @@ int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uin
   ctx->key_loaded = false;
   if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, polys * kN * sizeof(double)));
   if (!ctx->d_ksk)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4));
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
   if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
   CHK(to_dev(ctx, ctx->h_a, key_lv0, (size_t)P.n * 4));
   CHK(to_dev(ctx, ctx->h_b, key_lv1, (size_t)kN * 4));
