@@ -297,6 +297,74 @@ def test_other_parameter_sets_bit_exact(O):
         assert np.array_equal(tr, O.batch_blind_rotate(ck, ca[:3]))
 
 
+def test_full_size_pbs_uint4(O, keys_uint4):
+    """BASELINE configs[3] at full size: 65,536 LutBootstrap::bootstrap_lut (m = 16, f = x^2 mod 16),
+    SECURITY_UINT4, device-resident.  Properties: every output decrypts to f(message); identical inputs at
+    different batch positions give bit-identical outputs; a sampled slice decrypts identically on the CPU path."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys_uint4
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    B, base = 65536, 512
+    rng = np.random.default_rng(44)
+    msgs0 = rng.integers(0, 16, base)
+    cts0 = sk.encrypt_lwe_message(msgs0, 16, 4401)
+    cts = np.tile(cts0, (B // base, 1))
+    lut = R.lut.Generator(16).generate_lookup_table(lambda x: (x * x) % 16)
+    dev = torch.device("cuda:0")
+    tin = torch.from_numpy(cts.view(np.int32)).to(dev)
+    tlut = torch.from_numpy(lut.poly.view(np.int32)).to(dev)
+    tout = torch.empty_like(tin)
+    eng.batch_bootstrap_dev(tin, tout, testvec=tlut)
+    torch.cuda.synchronize()
+    out = tout.cpu().numpy().view(np.uint32)
+    n = pk.params.n
+    assert np.array_equal(out.reshape(B // base, base, n + 1), np.broadcast_to(out[:base], (B // base, base, n + 1)))
+    # vectorised decrypt_lwe_message (tlwe.rs:111-126) of the first block
+    phase = out[:base, n] - (out[:base, :n] * sk.key_lv0[None, :]).sum(axis=1, dtype=np.uint32)
+    dec = ((phase.astype(np.float64) / 2.0**32) * 32.0 + 0.5).astype(np.int64) % 16
+    assert np.array_equal(dec, (msgs0 * msgs0) % 16)
+    cpu = O.batch_bootstrap(ck, cts0[:8], testvec=lut.poly)
+    assert np.array_equal(sk.decrypt_lwe_message(cpu, 16), sk.decrypt_lwe_message(out[:8], 16))
+
+
+def test_full_size_mixed_circuit_80bit(O, keys80):
+    """BASELINE configs[4] shape on one GPU: a mixed mux + xor circuit at SECURITY_80_BIT over a
+    65,536-wide batch (65,536 mux_naive = 196,608 gates + 65,536 xor), two launches in all."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys80
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    B, base = 65536, 256
+    rng = np.random.default_rng(45)
+    bits = rng.integers(0, 2, (3, base)).astype(bool)
+    ins0 = np.stack([sk.encrypt_bool(bits[w], 4500 + w) for w in range(3)])  # [3][base][n+1]
+    ins = np.tile(ins0, (1, B // base, 1))
+    c = R.Circuit(3)
+    w_mux = c.mux_naive(0, 1, 2)
+    w_xor = c.xor(0, 1)
+    assert [len(l) for l in c.levels()] == [3, 1]
+    dev = torch.device("cuda:0")
+    wires = c.run_dev(eng, torch.from_numpy(ins.view(np.int32)).to(dev))
+    torch.cuda.synchronize()
+    n = pk.params.n
+    for w, want in ((w_mux, np.where(bits[0], bits[1], bits[2])), (w_xor, bits[0] ^ bits[1])):
+        out = wires[w].cpu().numpy().view(np.uint32)
+        phase = out[:, n] - (out[:, :n] * sk.key_lv0[None, :]).sum(axis=1, dtype=np.uint32)
+        assert np.array_equal(phase.view(np.int32) >= 0, np.tile(want, B // base))
+        assert np.array_equal(out[:base], out[B - base:])
+    ref = c.run_reference(lambda op, a, b: O.batch_gate(ck, op, a, b), ins0[:, :4])
+    assert np.array_equal(wires[w_mux][:4].cpu().numpy().view(np.uint32), ref[w_mux])
+
+
 # ---- mixed-gate batches and levelised circuits ---------------------------------------------
 def test_mixed_gate_batch(O, eng128, keys128):
     """Per-ciphertext gate selectors: one launch, ten different gates."""
