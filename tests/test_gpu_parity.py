@@ -297,6 +297,43 @@ def test_other_parameter_sets_bit_exact(O):
         assert np.array_equal(tr, O.batch_blind_rotate(ck, ca[:3]))
 
 
+def test_extreme_parameter_shapes(O):
+    """Boundary shapes of the run-time parametric engine: the largest supported LWE dimension
+    (n = 1279: 5-wave key-switch blocks, 20.9 KB of LDS per blind-rotate wave) and the smallest
+    (n = 1), with l = 2 and an odd key-switch depth; bit-exact vs the CPU path."""
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd.params import SecurityParams
+
+    for (n, l, bgbit, basebit, t, seed) in ((1279, 2, 8, 2, 5, 51), (1, 3, 6, 2, 3, 52), (64, 1, 16, 3, 4, 53)):
+        # a 2^15-wide digit needs the (near) noise-free key of the UINT sets (params.rs:235-260), or the
+        # phase noise itself wraps the torus and nothing is comparable
+        op = O.Params(f"EDGE_{n}", n, l, bgbit, basebit, t, 2.0e-5, 2.0e-8 if bgbit <= 10 else 2.2e-16)
+        sk, ck = O.keygen(op, seed)
+        pp = SecurityParams(op.name, 0, n, l, bgbit, basebit, t, op.alpha_lv0, op.alpha_lv1)
+        pk = R.CloudKey(pp, ck.bootstrapping_key, ck.key_switching_key, ck.decomposition_offset, ck.blind_rotate_testvec)
+        eng = R.Engine(pp, 0)
+        eng.load_cloud_key(pk)
+        rng = np.random.default_rng(seed)
+        a = rng.integers(0, 2**32, (3, n + 1), dtype=np.uint64).astype(np.uint32)
+        b = rng.integers(0, 2**32, (3, n + 1), dtype=np.uint64).astype(np.uint32)
+        got = eng.batch_gate(O.GATE_XOR, a, b)
+        exp = O.batch_gate(ck, O.GATE_XOR, a, b)
+        if bgbit + np.log2(2 * l) < 12:  # exact-product regime: 2l*N*(Bg/2)*2^31 < 2^52
+            assert np.array_equal(got, exp), (n, l, bgbit)
+        else:
+            # inexact f64 products: a one-LSB difference can flip a decomposition digit, which swaps
+            # in a different (uniformly random) key row -- ciphertext words then differ wholesale while
+            # the PHASE moves by a noise term only.  Compare phases, as for SECURITY_UINT4.
+            g_t, e_t = eng.batch_blind_rotate(a), O.batch_blind_rotate(ck, a)
+            for x, y in zip(g_t, e_t):
+                assert signed_diff(sk.trlwe_phase(x), sk.trlwe_phase(y)) < (1 << 24)
+        lv1 = rng.integers(0, 2**32, (5, N + 1), dtype=np.uint64).astype(np.uint32)
+        assert np.array_equal(eng.batch_identity_key_switch(lv1), np.stack([O.identity_key_switching(ck, x) for x in lv1]))
+        eng.close()
+    with pytest.raises(R._capi.TfheHipError):
+        R.Engine(SecurityParams("TOO_BIG", 0, 1280, 3, 6, 2, 9, 1e-5, 1e-8), 0)
+
+
 def test_full_size_pbs_uint4(O, keys_uint4):
     """BASELINE configs[3] at full size: 65,536 LutBootstrap::bootstrap_lut (m = 16, f = x^2 mod 16),
     SECURITY_UINT4, device-resident.  Properties: every output decrypts to f(message); identical inputs at
