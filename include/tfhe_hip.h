@@ -140,7 +140,9 @@ int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, cons
  * ciphertext pair c.  This is what a levelised circuit (e.g. the ripple-carry adder of
  * examples/add_two_numbers.rs) issues per level: every gate of the level in ONE launch,
  * whatever its type.  Same semantics as count calls of the Gates method
- * (src/gates.rs:54-150); b is read for every gate but COPY. */
+ * (src/gates.rs:54-150); b is read for every gate but COPY.  The host entry rejects codes
+ * above TFHE_HIP_COPY with TFHE_HIP_EINVAL; the _dev entry cannot read device memory on the
+ * host and treats them as COPY. */
 int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
                                const uint32_t *b, uint32_t *out, size_t count);
 int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
