@@ -66,10 +66,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    # BENCH_SHARE_GPU=1 is a plumbing self-test for boxes with fewer GPUs than ranks: ranks share
+    # devices (rank % device_count) and rendezvous over gloo, since RCCL refuses two ranks on one GPU.
+    share = os.environ.get("BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     P = R.params.PARAM_SETS[args.params]
     OP = O.PARAM_SETS[args.params]
@@ -133,7 +141,7 @@ def main():
     kt = eng.kernel_times()
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
