@@ -143,10 +143,12 @@ __device__ __forceinline__ void cmul(double &xr, double &xi, double wr, double w
   xi = i;
 }
 
-// The single-wave workgroup's LDS hand-off: orders this wave's LDS writes
-// before its LDS reads (other lanes' data).  With one wave per workgroup the
-// barrier itself is free; what matters is the lgkmcnt wait + compiler fence.
-__device__ __forceinline__ void wave_lds_sync() { __syncthreads(); }
+// LDS hand-off WITHIN one wavefront: orders this wave's LDS writes before its later LDS reads of
+// other lanes' data.  LDS operations of a wave execute in program order, so the hardware needs no
+// barrier; what is needed is that the compiler keeps the order (memory clobber) and that pending
+// reads have returned before their registers are reused (lgkmcnt).  It involves no other wave, so
+// the same FFT code serves one-wave workgroups and the multi-wave latency kernel.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // Forward transform.  In: re/im[m] = fold of coefficients (l+64m, l+64m+512),
 // NOT yet twisted.  Out: re/im[s] = bin (mu>>3)+8*(mu&7)+64*s, unscaled.

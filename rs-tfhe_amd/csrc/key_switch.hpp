@@ -268,6 +268,53 @@ __global__ __launch_bounds__(320) void k_key_switch_b4(const uint32_t *__restric
   }
 }
 
+// ---- small batches: the walk over i split across workgroups ---------------------------------
+// The group kernels above walk all N*t (i, j) pairs inside one workgroup -- right for a full
+// machine, but ~10 ms of serial latency when only a handful of ciphertexts exist.  Here a
+// ciphertext's N coefficients are cut into `gridDim.y` slices; each workgroup subtracts the rows of
+// its slice into registers and merges them into the (pre-zeroed) output with integer atomics.
+// u32 addition is associative and commutative, so the result is the same bits in any arrival order.
+__global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__restrict__ lv1,  // [count][N+1]
+                                                           const uint4 *__restrict__ ksk,     // engine layout
+                                                           uint32_t ksk_bytes, int n, int basebit, int t,
+                                                           uint32_t *__restrict__ out) {      // [count][n+1], zeroed
+  constexpr int N = 1024;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  const int rw4 = ksk_row_words(n) >> 2;
+  const size_t ct = blockIdx.x;
+  const int slices = gridDim.y, per = N / slices;  // host picks a divisor of N
+  const int i_lo = blockIdx.y * per;
+  const int tid = threadIdx.x;
+  const uint32_t lane_off = (tid < rw4 ? (uint32_t)tid : 0u) * 16u;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void *)ksk, 0, (int)ksk_bytes, 0x00020000);
+  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+  const uint32_t base = 1u << basebit, mask = base - 1u;
+  const uint32_t row_bytes = (uint32_t)rw4 * 16u;
+  u32x4 acc = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll 1
+  for (int i = i_lo; i < i_lo + per; ++i) {
+    const uint32_t ab = (uint32_t)__builtin_amdgcn_readfirstlane(lv1[ct * (N + 1) + i]) + prec_offset;
+#pragma unroll 4
+    for (int j = 0; j < t; ++j) {
+      const uint32_t k = (ab >> (32 - (j + 1) * basebit)) & mask;
+      // k == 0 rows are zero in the engine layout: branch-free
+      acc -= __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)((((uint32_t)i * t + j) * base + k) * row_bytes), 0);
+    }
+  }
+  if (tid < rw4) {
+    uint32_t *o = out + ct * (size_t)(n + 1);
+    const uint32_t w[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int x = 4 * tid + c;
+      uint32_t v = w[c];
+      if (x == n && blockIdx.y == 0) v += lv1[ct * (N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+      if (x <= n && v) atomicAdd(o + x, v);
+    }
+  }
+}
+
 // reference layout [N*t*base][n+1] -> engine layout [N*t*base][RW], k == 0 rows and pads zeroed
 __global__ void k_ksk_convert(const uint32_t *__restrict__ ref, uint32_t *__restrict__ eng, int n, int base,
                               size_t rows) {

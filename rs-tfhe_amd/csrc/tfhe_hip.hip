@@ -53,6 +53,9 @@ struct tfhe_hip_ctx {
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
   bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
+  bool br_wide = true;      // small batches use the latency kernels
+  size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
+  size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
@@ -182,6 +185,25 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.out_lv1 = out_lv1;
   A.out_ext2 = out_ext2;
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
+  // small batches: one workgroup of 2l waves per ciphertext (latency kernel)
+  if (ctx->br_wide && count <= ctx->wide_max) {
+    typedef void (*wide_kernel_t)(BlindRotateArgs);
+    wide_kernel_t kern;
+    const bool f = ctx->fast_round;
+    switch (ctx->P.l) {
+      case 1: kern = f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>; break;
+      case 2: kern = f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>; break;
+      default: kern = f ? k_blind_rotate_wide<3, true> : k_blind_rotate_wide<3, false>; break;
+    }
+    const size_t wlds = blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
+    CHK(record_begin(ctx, s, ctx->ev_br));
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(128 * ctx->P.l), wlds, s, A);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_br));
+    ctx->bootstraps += count;
+    return TFHE_HIP_OK;
+  }
   dim3 block(64);
   size_t lds = br_lds_bytes(ctx);
   // Launch in rounds of exactly the resident set: every workgroup of a round starts
@@ -225,6 +247,16 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
   dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
   CHK(record_begin(ctx, s, ctx->ev_ks));
+  if (ctx->br_wide && count <= ctx->ks_split_max) {
+    // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
+    const size_t kb = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
+    HIPCHK(ctx, hipMemsetAsync(out, 0, count * (size_t)(n + 1) * 4, s));
+    hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->d_ksk,
+                       (uint32_t)kb, n, ctx->P.basebit, ctx->P.t, out);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_ks));
+    return TFHE_HIP_OK;
+  }
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
   const size_t b4_lds = ks_b4_lds_bytes(n, kKsG);
   const bool b4_fits = (ks_b4_slot_bytes(n) >> 10) <= (uint32_t)(kKsChunksPerWave * (bd >> 6)) && b4_lds <= 64 * 1024;
@@ -385,6 +417,11 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
+  ctx->wide_max = 2 * (size_t)ctx->num_cus;      // measured crossover vs the batch kernel: ~640 ciphertexts
+  ctx->ks_split_max = 32 * (size_t)ctx->num_cus;  // measured crossover vs the group kernels: ~12k ciphertexts
+  if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
+  if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
   std::vector<double2> tw;
   make_twiddles(tw);

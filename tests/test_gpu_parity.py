@@ -402,6 +402,32 @@ def test_full_size_mixed_circuit_80bit(O, keys80):
     assert np.array_equal(wires[w_mux][:4].cpu().numpy().view(np.uint32), ref[w_mux])
 
 
+def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
+    """Batches <= #CUs go through the 2l-waves-per-ciphertext latency kernel, larger ones through the
+    one-wave-per-ciphertext batch kernel: both must give the oracle's bits, for every output form."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    rng = np.random.default_rng(46)
+    A = rng.integers(0, 2, 40).astype(bool)
+    B = rng.integers(0, 2, 40).astype(bool)
+    ca, cb = sk.encrypt_bool(A, 4600), sk.encrypt_bool(B, 4601)
+    outs = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("TFHE_HIP_BR_WIDE", wide)
+        eng = R.Engine(pk.params, 0)
+        eng.load_cloud_key(pk)
+        outs[wide] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
+                      eng.batch_bootstrap(ca[:5], keyswitch=False), eng.batch_gates_mixed(np.arange(40, dtype=np.uint8) % 10, ca, cb))
+        eng.close()
+    for x, y in zip(outs["1"], outs["0"]):
+        assert np.array_equal(x, y)
+    assert np.array_equal(outs["1"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
+    assert np.array_equal(outs["1"][1], O.batch_blind_rotate(ck, ca[:5]))
+    assert np.array_equal(outs["1"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+
+
 # ---- mixed-gate batches and levelised circuits ---------------------------------------------
 def test_mixed_gate_batch(O, eng128, keys128):
     """Per-ciphertext gate selectors: one launch, ten different gates."""
