@@ -195,6 +195,22 @@ def main():
         "whole_path_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
         "whole_path_frac": round(value / world * bytes_per_bootstrap / 8e12, 4),
     }
+    # Secondary, physical bound: the key is shared through L2, so the kernel is
+    # limited by f64 VALU issue, not HBM.  Instruction counts per CMUX step are read off the gfx950 ISA
+    # of k_blind_rotate (`make report`, profiles/README.md): per digit row 372 VALU (164 add + 75 mul +
+    # 100 fma f64), per step another 750 (296 add + 86 mul + 136 fma f64 in the two inverse FFTs).
+    if br_ms > 0:
+        steps_per_s = P.n * per_launch / (br_ms * 1e-3)
+        flops_per_step = 64 * (2 * P.l * (164 + 75 + 2 * 100) + (296 + 86 + 2 * 136))
+        valu_per_step = 2 * P.l * 372 + 750
+        simd_cycles_per_s = 256 * 4 * 2.4e9  # 256 CUs x 4 SIMDs; one wave64 VALU op = 4 cycles
+        roofline["fp64_valu"] = {
+            "achieved": round(steps_per_s * flops_per_step / 1e12, 2),
+            "peak": 78.6,
+            "unit": "TFLOP/s",
+            "frac": round(steps_per_s * flops_per_step / 78.6e12, 4),
+            "valu_issue_frac": round(steps_per_s * valu_per_step * 4 / simd_cycles_per_s, 4),
+        }
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline and not special:
