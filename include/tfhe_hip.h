@@ -30,7 +30,10 @@
  * case they are device pointers on the context's GPU and the call is enqueued
  * on `stream` (a hipStream_t passed as void*; NULL = the context's own non-blocking
  * stream; pass hipStreamLegacy, i.e. (hipStream_t)1, to name the default stream)
- * without synchronising.
+ * without synchronising.  Intermediate buffers belong to the context: when a
+ * call arrives on a different stream than the previous one, the library first
+ * drains the previous stream (hipStreamSynchronize), so mixing streams on one
+ * context is safe but serialising; use one context per stream for overlap.
  *
  * Thread safety: a context may be used from several host threads (the
  * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23); calls on one

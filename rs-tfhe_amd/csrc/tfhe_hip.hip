@@ -59,6 +59,8 @@ struct tfhe_hip_ctx {
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
+  hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
+  bool scratch_owned = false;
 };
 
 #define HIPCHK(ctx, call)                                                                   \
@@ -278,12 +280,23 @@ int need_key(tfhe_hip_ctx *ctx) {
 
 hipStream_t pick(tfhe_hip_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
+// The intermediate buffers (lv1, u1, u2) belong to the context, not to a call.  Work queued on one
+// stream may still be using them when the next call arrives on another stream: drain the previous
+// owner first (same-stream calls are ordered by the stream itself and pay nothing).
+int claim_scratch(tfhe_hip_ctx *ctx, hipStream_t s) {
+  if (ctx->scratch_owned && ctx->scratch_owner != s) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  ctx->scratch_owner = s;
+  ctx->scratch_owned = true;
+  return TFHE_HIP_OK;
+}
+
 // ---- device-pointer implementations (mutex held by caller) -------------------
 
 int gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
              size_t count, hipStream_t s) {
   GatePrep gp;
   if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
+  CHK(claim_scratch(ctx, s));
   CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
@@ -292,6 +305,7 @@ int gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b, 
 int gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b, uint32_t *out,
                     size_t count, hipStream_t s) {
   GatePrep gp{1u, 1u, 0u};  // placeholders; cb != 0 keeps in_b attached, the kernel reads the codes
+  CHK(claim_scratch(ctx, s));
   CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr, gates));
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
@@ -302,6 +316,7 @@ int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec
   GatePrep gp;
   gate_prep(TFHE_HIP_COPY, gp);
   if (keyswitch) {
+    CHK(claim_scratch(ctx, s));
     CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
     CHK(launch_blind_rotate(ctx, s, in, nullptr, gp, testvec, per_ct, count, nullptr,
                             (uint32_t *)ctx->lv1.p, nullptr));
@@ -313,6 +328,7 @@ int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec
 int mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c,
             uint32_t *out, size_t count, hipStream_t s) {
   const size_t ctb = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(claim_scratch(ctx, s));
   CHK(ensure(ctx, ctx->u1, ctb));
   CHK(ensure(ctx, ctx->u2, ctb));
   uint32_t *u1 = (uint32_t *)ctx->u1.p, *u2 = (uint32_t *)ctx->u2.p;

@@ -653,3 +653,36 @@ def test_device_resident_full_batch_properties(O, eng128, keys128):
     # linearity of the integer tail: keyswitch(x) - keyswitch(y) == keyswitch-sum identity on b only
     kt = eng128.kernel_times()
     assert kt["bootstraps"] >= 0
+
+
+def test_calls_on_different_streams_share_one_context(O, eng128, keys128):
+    """Back-to-back asynchronous calls on different streams (torch default, a side stream, the
+    context's own stream via the host API) reuse the context's intermediate buffers; none may
+    clobber another's in-flight data (include/tfhe_hip.h, stream semantics)."""
+    import torch
+
+    sk, ck = keys128
+    rng = np.random.default_rng(31)
+    B = 3000  # large enough that each call is still running when the next is issued
+    dev = torch.device("cuda:0")
+    sets = []
+    for i in range(3):
+        A = rng.integers(0, 2, B).astype(bool)
+        Bb = rng.integers(0, 2, B).astype(bool)
+        ca, cb = sk.encrypt_bool(A, 3100 + 2 * i), sk.encrypt_bool(Bb, 3101 + 2 * i)
+        sets.append((A, Bb, ca, cb))
+    t = [(torch.from_numpy(ca.view(np.int32)).to(dev), torch.from_numpy(cb.view(np.int32)).to(dev)) for _, _, ca, cb in sets]
+    outs = [torch.empty_like(x[0]) for x in t]
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    eng128.batch_gate_dev(O.GATE_NAND, t[0][0], t[0][1], outs[0])  # torch default stream
+    with torch.cuda.stream(side):
+        eng128.batch_gate_dev(O.GATE_XOR, t[1][0], t[1][1], outs[1])  # side stream
+    host_out = eng128.batch_gate(O.GATE_OR, sets[2][2], sets[2][3])  # context's own stream, blocking
+    torch.cuda.synchronize()
+    got = [outs[0].cpu().numpy().view(np.uint32), outs[1].cpu().numpy().view(np.uint32), host_out]
+    truth = [~(sets[0][0] & sets[0][1]), sets[1][0] ^ sets[1][1], sets[2][0] | sets[2][1]]
+    for g, w in zip(got, truth):
+        assert np.array_equal(sk.decrypt_bool(g), w)
+    for g, gate, (_, _, ca, cb) in zip(got, (O.GATE_NAND, O.GATE_XOR, O.GATE_OR), sets):
+        assert np.array_equal(g[:16], O.batch_gate(ck, gate, ca[:16], cb[:16]))
