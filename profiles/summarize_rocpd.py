@@ -11,7 +11,7 @@ import os
 import sqlite3
 import sys
 
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.environ.get("PROFILE_OUT") or os.path.dirname(os.path.abspath(__file__))  # PROFILE_OUT: write elsewhere
 
 
 def kernel_stats(db, out):

@@ -112,12 +112,16 @@ __global__ __launch_bounds__(320) void k_key_switch(const uint32_t *__restrict__
 // With basebit = 2 (the 80/110/128-bit and UINT1 sets) a group (i, j) has only three non-zero
 // candidate rows, and all G ciphertexts of a workgroup pick among them.  k_key_switch sends every
 // pick through the vector L1 (64 B/clk/CU -- its measured bound).  Here the three rows of a group
-// are copied ONCE into LDS by `global_load_lds_dwordx4` (no VGPRs, contiguous 1 KiB per wave
-// instruction), NS-1 groups ahead of their use, and every pick is a ds_read_b128 (256 B/clk/CU).
-// Hand-off per group: each wave waits for its own DMAs of that group with a COUNTED s_waitcnt
-// vmcnt (younger groups stay in flight across the barrier), one s_barrier makes all waves'
-// pieces visible and frees the slot of the previous group, which the next DMA then refills.
-// The DMA is inline asm so that hipcc neither drains it with vmcnt(0) at LDS reads nor at barriers.
+// are copied ONCE into LDS by `global_load_lds_dwordx4` (no VGPRs, 1 KiB per wave instruction),
+// NS-1 groups ahead of their use, and every pick is a ds_read_b128.
+// A lane only ever needs its own four columns, so each WAVE copies and consumes its own 1 KiB
+// column band of every row: the ring is wave-private, the hand-off is a COUNTED s_waitcnt vmcnt on
+// the wave's own DMAs (younger groups stay in flight) and there is no barrier in the group loop.
+// What bounds the loop is instruction issue (one per wave per 4 cycles, one scalar unit per CU):
+// the pick is kept to s_bfe + s_mul (row = slot + k * stride, each slot carrying its own zero row
+// for k = 0) + two vector address adds + ds_read_b128 + 4 v_sub.  r1d spent 261 scalar instructions
+// per group on a select-based pick and ran 38 ms; this form issues ~100 and runs 23 ms.
+// The DMA is inline asm so that hipcc does not drain it with vmcnt(0) at every LDS read.
 __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
   uint32_t keep;
   asm volatile(
@@ -135,56 +139,65 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
 #define TFHE_KS_NS 3
 #endif
 constexpr int kKsRingSlots = TFHE_KS_NS;  // NS: groups resident in LDS
-constexpr int kKsChunksPerWave = 3;  // CW: DMA instructions per wave per group (1 KiB each)
+#ifndef TFHE_KS_STAGE
+#define TFHE_KS_STAGE 64
+#endif
+constexpr int kKsStage = TFHE_KS_STAGE;   // coefficients whose a_bar words are staged in LDS at a time
+constexpr uint32_t kKsWaveBytes = 1024;   // one DMA instruction: 64 lanes x 16 B = this wave's columns of one row
 
-__host__ __device__ __forceinline__ uint32_t ks_b4_slot_bytes(int n) {
-  return ((uint32_t)ksk_row_words(n) * 4u * 3u + 1023u) & ~1023u;
-}
-__host__ __device__ __forceinline__ size_t ks_b4_lds_bytes(int n, int G) {
-  // zero row | dummy chunk | ring | a_bar staging
-  return (size_t)ksk_row_words(n) * 4 + 1024 + (size_t)kKsRingSlots * ks_b4_slot_bytes(n) + (size_t)G * 64 * 4;
+// LDS per workgroup of `nw` waves: ring[NS][zero row, 3 rows][nw KiB] | a_bar staging.  Each wave
+// owns the 1 KiB column band [w KiB, (w+1) KiB) of every row, so rows sit at a stride of nw KiB; every
+// slot starts with its own zero row so that the row picked by digit k is simply slot + k * stride.
+__host__ __device__ __forceinline__ uint32_t ks_b4_row_stride(int nw) { return (uint32_t)nw * kKsWaveBytes; }
+__host__ __device__ __forceinline__ uint32_t ks_b4_slot_bytes(int nw) { return 4u * ks_b4_row_stride(nw); }
+__host__ __device__ __forceinline__ size_t ks_b4_lds_bytes(int nw, int G) {
+  return (size_t)kKsRingSlots * ks_b4_slot_bytes(nw) + (size_t)G * kKsStage * 4;
 }
 
 template <int G>
-__global__ __launch_bounds__(320) void k_key_switch_b4(const uint32_t *__restrict__ lv1,  // [count][N+1]
+__global__ __launch_bounds__(320) __attribute__((amdgpu_waves_per_eu(3))) void k_key_switch_b4(const uint32_t *__restrict__ lv1,  // [count][N+1]
                                                         const unsigned char *__restrict__ ksk,  // engine layout
                                                         int n, int t, uint32_t *__restrict__ out,
                                                         size_t count) {
-  constexpr int N = 1024, IC = 64, NS = kKsRingSlots, D = NS - 1, CW = kKsChunksPerWave;
+  constexpr int N = 1024, IC = kKsStage, NS = kKsRingSlots, D = NS - 1;
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned char ks_smem[];
   const int rw4 = ksk_row_words(n) >> 2;
   const uint32_t row_bytes = (uint32_t)rw4 * 16u;
-  const uint32_t slot_bytes = ks_b4_slot_bytes(n);
-  const uint32_t chunks = slot_bytes >> 10;
-  // LDS carve (byte offsets from the dynamic base)
-  const uint32_t off_zero = 0u, off_dummy = row_bytes, off_ring = row_bytes + 1024u;
-  const uint32_t off_ab = off_ring + NS * slot_bytes;
-  uint32_t(*s_ab)[IC] = reinterpret_cast<uint32_t(*)[IC]>(ks_smem + off_ab);
-  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ks_smem;
-
-  const size_t g0 = (size_t)blockIdx.x * G;
   const int tid = threadIdx.x;
   const int bd = blockDim.x;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t nw = (uint32_t)(bd >> 6);
   const uint32_t lane = (uint32_t)(tid & 63);
-  const uint32_t xoff = (tid < rw4 ? (uint32_t)tid : 0u) * 16u;
+  const uint32_t row_stride = ks_b4_row_stride((int)nw);
+  const uint32_t slot_bytes = 4u * row_stride;
+  // LDS carve (byte offsets from the dynamic base)
+  const uint32_t off_ring = 0u;
+  const uint32_t off_ab = off_ring + NS * slot_bytes;
+  uint32_t(*s_ab)[IC] = reinterpret_cast<uint32_t(*)[IC]>(ks_smem + off_ab);
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)ks_smem;
+
+  const size_t g0 = (size_t)blockIdx.x * G;
+  const uint32_t xoff = (uint32_t)tid * 16u;  // this lane's 4 columns, in a row and in every LDS copy of one
   const uint32_t prec_offset = 1u << (32 - (1 + 2 * t));
   const uint32_t total = (uint32_t)N * (uint32_t)t;
 
-  for (int x = tid; x < rw4; x += bd) reinterpret_cast<u32x4 *>(ks_smem + off_zero)[x] = u32x4{0u, 0u, 0u, 0u};
+  for (int sl = 0; sl < NS; ++sl)  // row 0 of every slot: the k == 0 pick
+    for (int x = tid; x < (int)(row_stride >> 4); x += bd)
+      reinterpret_cast<u32x4 *>(ks_smem + off_ring + sl * slot_bytes)[x] = u32x4{0u, 0u, 0u, 0u};
 
-  // the three non-zero rows of group q are contiguous: bytes [(4q+1)*row_bytes, (4q+4)*row_bytes)
+  // Group q = (i, j): its three non-zero rows are rows 4q+1 .. 4q+3 of the key.  This wave copies ITS
+  // column band of each (bytes past the row end belong to the next row or the allocation's tail pad and
+  // only ever reach lanes whose columns are never stored).  Past the last group the source is clamped:
+  // every wave still issues exactly three DMAs per group, so the counted waits below stay exact.
   auto dma_group = [&](uint32_t q) {
     const uint32_t slot = q % NS;
+    const uint32_t qs = q < total ? q : total - 1u;
 #pragma unroll
-    for (int c = 0; c < CW; ++c) {
-      const uint32_t chunk = wave + (uint32_t)c * nw;  // wave-uniform
-      const bool real = (chunk < chunks) & (q < total);
-      const size_t gofs = real ? ((size_t)(4u * q + 1u) * row_bytes + (size_t)chunk * 1024u) : 0;
-      const uint32_t dst = real ? (off_ring + slot * slot_bytes + chunk * 1024u) : off_dummy;
-      glds16(ksk + gofs + lane * 16u, lds_base + dst);  // every wave issues exactly CW DMAs per group
+    for (uint32_t c = 0; c < 3u; ++c) {
+      const size_t gofs = (size_t)(4u * qs + 1u + c) * row_bytes + (size_t)wave * kKsWaveBytes;
+      const uint32_t dst = off_ring + slot * slot_bytes + (c + 1u) * row_stride + wave * kKsWaveBytes;
+      glds16(ksk + gofs + lane * 16u, lds_base + dst);
     }
   };
 
@@ -215,32 +228,24 @@ __global__ __launch_bounds__(320) void k_key_switch_b4(const uint32_t *__restric
       for (int g = 0; g < G; ++g) ab[g] = __builtin_amdgcn_readfirstlane(s_ab[g][ii]);
 #pragma unroll 1
       for (int j = 0; j < t; ++j, ++q) {
-        // this wave's pieces of group q have landed: at most the D-1 younger groups stay in flight
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * CW) : "memory");
-        __builtin_amdgcn_s_barrier();  // all pieces of q visible; everyone is done with group q-1
-        asm volatile("" ::: "memory");
-        dma_group(q + (uint32_t)D);    // refill the slot group q-1 just vacated
+        // this wave's band of group q has landed (at most the D-1 younger groups stay in flight); no
+        // other wave reads or writes it, so there is no barrier; the slot refilled next is the one this
+        // wave finished reading in the previous iteration (its subtractions consumed the reads)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 3) : "memory");
+        dma_group(q + (uint32_t)D);
         const int sh = 32 - (j + 1) * 2;
         const uint32_t slot_off = off_ring + (q % NS) * slot_bytes;
-        constexpr int GB = G < 16 ? G : 16;  // LDS reads in flight per lane before their subtractions
+        const uint32_t bfe_arg = (uint32_t)sh | (2u << 16);  // offset | width << 16
+        constexpr int GB = G < 8 ? G : 8;  // LDS reads in flight per lane before their subtractions (registers: 3 waves per SIMD)
 #pragma unroll
         for (int gb = 0; gb < G; gb += GB) {
           u32x4 v[GB];
 #pragma unroll
           for (int g = 0; g < GB; ++g) {
-            const uint32_t k = (ab[gb + g] >> sh) & 3u;
-            // roff = k ? slot_off + (k-1)*row_bytes : off_zero (= 0), wave-uniform.  Written as SALU
-            // asm: left to itself hipcc does this select per lane (v_mul_lo_u32 + v_cndmask + 2 adds
-            // for every pick), which made the kernel VALU-bound.
-            uint32_t roff;
-            asm("s_sub_u32 %0, %1, 1\n\t"
-                "s_mul_i32 %0, %0, %2\n\t"
-                "s_add_u32 %0, %0, %3\n\t"
-                "s_cmp_eq_u32 %1, 0\n\t"
-                "s_cselect_b32 %0, 0, %0"
-                : "=&s"(roff)
-                : "s"(k), "s"(row_bytes), "s"(slot_off)
-                : "scc");
+            // wave-uniform pick: two scalar instructions (bfe, mul) and two vector address adds per row
+            uint32_t k;  // s_bfe_u32 (hipcc emits shift + and, or v_bfe_u32 for the builtin)
+            asm("s_bfe_u32 %0, %1, %2" : "=s"(k) : "s"(ab[gb + g]), "s"(bfe_arg) : "scc");
+            const uint32_t roff = slot_off + k * row_stride;
             v[g] = *reinterpret_cast<const u32x4 *>(ks_smem + roff + xoff);
           }
 #pragma unroll
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(320) void k_key_switch_b4(const uint32_t *__restric
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (dummy) DMAs before the LDS goes away
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (clamped) DMAs before the LDS goes away
   if (tid < rw4) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {

@@ -260,8 +260,8 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
     return TFHE_HIP_OK;
   }
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
-  const size_t b4_lds = ks_b4_lds_bytes(n, kKsG);
-  const bool b4_fits = (ks_b4_slot_bytes(n) >> 10) <= (uint32_t)(kKsChunksPerWave * (bd >> 6)) && b4_lds <= 64 * 1024;
+  const size_t b4_lds = ks_b4_lds_bytes(bd >> 6, kKsG);
+  const bool b4_fits = b4_lds <= 64 * 1024;
   if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
     hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
                        ctx->P.t, out, count);
