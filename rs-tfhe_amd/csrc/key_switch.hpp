@@ -41,7 +41,6 @@ __global__ __launch_bounds__(320) void k_key_switch(const uint32_t *__restrict__
       __builtin_amdgcn_make_buffer_rsrc((void *)ksk, 0, (int)ksk_bytes, 0x00020000);
   const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
   const uint32_t base = 1u << basebit;
-  const uint32_t mask = base - 1u;
 
   uint4 acc[G];
 #pragma unroll
@@ -68,6 +67,8 @@ __global__ __launch_bounds__(320) void k_key_switch(const uint32_t *__restrict__
 #pragma unroll 1
       for (int j = 0; j < t; ++j, grp += base) {
         const int sh = 32 - (j + 1) * basebit;
+        const uint32_t bfe_arg = (uint32_t)sh | ((uint32_t)basebit << 16);  // offset | width << 16
+        const uint32_t grp_bytes = grp * row_bytes;
         // GB row loads in flight per lane at a time (register budget: acc 4G + v 4GB)
         constexpr int GB = G < 16 ? G : 16;
 #pragma unroll
@@ -75,9 +76,10 @@ __global__ __launch_bounds__(320) void k_key_switch(const uint32_t *__restrict__
           u32x4 v[GB];
 #pragma unroll
           for (int g = 0; g < GB; ++g) {
-            const uint32_t k = (ab[gb + g] >> sh) & mask;
+            uint32_t k;  // scalar bit-field extract (hipcc emits shift + and)
+            asm("s_bfe_u32 %0, %1, %2" : "=s"(k) : "s"(ab[gb + g]), "s"(bfe_arg) : "scc");
             // one descriptor, lane offset in a VGPR, row offset in an SGPR: no per-lane address math
-            v[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)((grp + k) * row_bytes), 0);
+            v[g] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)(grp_bytes + k * row_bytes), 0);
           }
 #pragma unroll
           for (int g = 0; g < GB; ++g) {
