@@ -322,6 +322,139 @@ __global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__rest
   }
 }
 
+// ---- column-sliced variant for wider bases (basebit 3..7: the UINT2..UINT7 sets) ---------------------
+// With base = 32 nearly every ciphertext of a group picks a different candidate row, so k_key_switch
+// fetches a whole 3.3 KB row from L2 for every (ciphertext, group): 662 GB per 65,536-batch at
+// SECURITY_UINT4, L2-bandwidth bound (49 ms).  Here a workgroup owns a SLICE of 64 output columns for
+// 512 ciphertexts: all `base` candidate rows of a group, cut to that slice (base x 256 B), are copied
+// once into an LDS ring by global_load_lds and every ciphertext picks from LDS.  L2 traffic falls by
+// the ciphertexts-per-workgroup ratio (42 GB at UINT4).
+// Lane map: 16 lanes cover the 64 columns (4 each); the 4 lane-quarters of a wave serve 4 different
+// ciphertexts per instruction (ds_read_b128 is serviced in 16-lane groups, so different rows per quarter
+// cost nothing); S accumulator sets per lane -> 4*S ciphertexts per wave, 16*S per workgroup of 4 waves.
+// The digit is per quarter, so the pick is two VALU instructions (v_bfe_u32, v_lshl_add_u32).
+constexpr int kKsSlSets = 32;      // S: accumulator sets per lane
+constexpr int kKsSlWaves = 4;
+constexpr int kKsSlCts = 4 * kKsSlSets * kKsSlWaves;  // ciphertexts per workgroup (512)
+constexpr int kKsSlStage = 16;      // coefficients whose a_bar words are staged in LDS at a time
+constexpr int kKsSlSlots = 3;      // ring depth
+
+__host__ __device__ __forceinline__ uint32_t ks_sliced_slot_bytes(int base) {
+  return (uint32_t)((base + 15) & ~15) * 256u;  // whole DMA instructions: 4 rows each, 4 waves
+}
+__host__ __device__ __forceinline__ size_t ks_sliced_lds_bytes(int base) {
+  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)kKsSlCts * kKsSlStage * 4;
+}
+
+__global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__restrict__ lv1,  // [count][N+1]
+                                                            const unsigned char *__restrict__ ksk,  // engine layout
+                                                            int n, int basebit, int t,
+                                                            uint32_t *__restrict__ out, size_t count) {
+  constexpr int N = 1024, S = kKsSlSets, IC = kKsSlStage, NS = kKsSlSlots, D = NS - 1;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+  extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
+  const uint32_t base = 1u << basebit;
+  const uint32_t row_bytes = (uint32_t)ksk_row_words(n) * 4u;
+  const uint32_t slot_bytes = ks_sliced_slot_bytes((int)base);
+  const uint32_t cw = slot_bytes >> 12;  // DMA instructions per wave per group (1 KiB = 4 row slices each)
+  const uint32_t off_ab = NS * slot_bytes;
+  uint32_t(*s_ab)[IC] = reinterpret_cast<uint32_t(*)[IC]>(sl_smem + off_ab);  // [ciphertext][coefficient]
+  const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)sl_smem;
+
+  const int tid = threadIdx.x;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lane = (uint32_t)(tid & 63);
+  const uint32_t sub = lane >> 4, c4 = lane & 15u;
+  const size_t ct0 = (size_t)blockIdx.x * kKsSlCts;
+  const uint32_t col0 = blockIdx.y * 64u;  // first column of this slice
+  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+  const uint32_t total = (uint32_t)N * (uint32_t)t;
+  const uint32_t total_rows = total * base;
+
+  // group q: rows q*base .. q*base+base-1; DMA instruction x of a group moves row slices 4x..4x+3
+  // (lane quarter = row, 16 lanes x 16 B = the 256-byte slice).  Rows past the group (padding up to a
+  // whole instruction) and past the key are clamped to a valid row: they land in LDS rows no digit selects.
+  auto dma_group = [&](uint32_t q) {
+    const uint32_t slot = q % NS;
+    for (uint32_t c = 0; c < cw; ++c) {
+      const uint32_t x = wave + c * kKsSlWaves;
+      uint32_t row = (q < total ? q : total - 1u) * base + 4u * x + sub;
+      row = row < total_rows ? row : total_rows - 1u;
+      const size_t gofs = (size_t)row * row_bytes + col0 * 4u + c4 * 16u;
+      glds16(ksk + gofs, lds_base + slot * slot_bytes + x * 1024u);
+    }
+  };
+
+  u32x4 acc[S];
+#pragma unroll
+  for (int a = 0; a < S; ++a) acc[a] = u32x4{0u, 0u, 0u, 0u};
+
+#pragma unroll 1
+  for (uint32_t d = 0; d < (uint32_t)D; ++d) dma_group(d);
+
+  uint32_t q = 0;
+#pragma unroll 1
+  for (int i0 = 0; i0 < N; i0 += IC) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int idx = tid; idx < kKsSlCts * IC; idx += 256) {
+      const int c = idx / IC, ii = idx % IC;
+      const size_t ct = ct0 + c;
+      s_ab[c][ii] = ct < count ? lv1[ct * (N + 1) + i0 + ii] + prec_offset : 0u;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ii = 0; ii < IC; ++ii) {
+      uint32_t ab[S];  // this lane quarter's ciphertexts: wave*4S + 4a + sub
+#pragma unroll
+      for (int a = 0; a < S; ++a) ab[a] = s_ab[wave * (4 * S) + 4 * a + sub][ii];
+#pragma unroll 1
+      for (int j = 0; j < t; ++j, ++q) {
+        // every wave issues exactly cw DMAs per group: this wave's pieces of group q have landed when at
+        // most the D-1 younger groups' are outstanding; the barrier makes all waves' pieces visible and
+        // retires group q-1, whose slot the next DMA refills
+        if (cw == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 1) : "memory");
+        else if (cw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2) : "memory");
+        else if (cw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 4) : "memory");
+        else if (cw == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 8) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dma_group(q + (uint32_t)D);
+        const uint32_t sh = 32u - (uint32_t)(j + 1) * (uint32_t)basebit;
+        const uint32_t lane_base = (q % NS) * slot_bytes + c4 * 16u;
+        constexpr int GB = 8;
+#pragma unroll
+        for (int gb = 0; gb < S; gb += GB) {
+          u32x4 v[GB];
+#pragma unroll
+          for (int g = 0; g < GB; ++g) {
+            const uint32_t k = __builtin_amdgcn_ubfe(ab[gb + g], sh, (uint32_t)basebit);
+            v[g] = *reinterpret_cast<const u32x4 *>(sl_smem + ((k << 8) + lane_base));
+          }
+#pragma unroll
+          for (int g = 0; g < GB; ++g) acc[gb + g] -= v[g];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < S; ++a) {
+    const size_t ct = ct0 + wave * (4 * S) + 4 * a + sub;
+    if (ct < count) {
+      uint32_t *o = out + ct * (size_t)(n + 1);
+      const uint32_t w[4] = {acc[a].x, acc[a].y, acc[a].z, acc[a].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int x = (int)(col0 + c4 * 4u) + c;
+        if (x < n) o[x] = w[c];
+        if (x == n) o[x] = w[c] + lv1[ct * (N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+      }
+    }
+  }
+}
+
 // reference layout [N*t*base][n+1] -> engine layout [N*t*base][RW], k == 0 rows and pads zeroed
 __global__ void k_ksk_convert(const uint32_t *__restrict__ ref, uint32_t *__restrict__ eng, int n, int base,
                               size_t rows) {

@@ -53,6 +53,7 @@ struct tfhe_hip_ctx {
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
   bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
+  int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
   bool br_wide = true;      // small batches use the latency kernels
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
@@ -262,7 +263,12 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
   const size_t b4_lds = ks_b4_lds_bytes(bd >> 6, kKsG);
   const bool b4_fits = b4_lds <= 64 * 1024;
-  if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
+  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);
+  if ((ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024) {
+    dim3 sgrid((unsigned)((count + kKsSlCts - 1) / kKsSlCts), (unsigned)((n + 1 + 63) / 64));
+    hipLaunchKernelGGL(k_key_switch_sliced, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+                       ctx->P.basebit, ctx->P.t, out, count);
+  } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
     hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
                        ctx->P.t, out, count);
   else
@@ -433,8 +439,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_KS_SLICED")) ctx->ks_sliced = atoi(env);
   ctx->wide_max = 2 * (size_t)ctx->num_cus;      // measured crossover vs the batch kernel: ~640 ciphertexts
-  ctx->ks_split_max = 32 * (size_t)ctx->num_cus;  // measured crossover vs the group kernels: ~12k ciphertexts
+  // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
+  ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);

@@ -125,6 +125,41 @@ def test_key_switch_bit_exact(O, eng128, keys128):
         assert np.array_equal(got, exp)
 
 
+@pytest.mark.parametrize("setname,env", [
+    ("SECURITY_128_BIT", {}),                                # k_key_switch_b4 (LDS ring, base 4)
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_B4": "0"}),           # k_key_switch (generic, buffer loads)
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_SLICED": "2"}),       # k_key_switch_sliced forced at base 4
+    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32)
+    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
+    ("SECURITY_UINT2", {}),                                  # base 16
+    ("SECURITY_UINT3", {}),                                  # base 64, t = 2
+])
+def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, env):
+    """Every batch key-switch kernel (the small-batch split kernel switched off), ragged counts that
+    cross the 32- and 512-ciphertext workgroup boundaries, against identity_key_switching
+    (trgsw.rs:332-360) word for word."""
+    import rs_tfhe_amd as R
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    monkeypatch.setenv("TFHE_HIP_KS_SPLIT_MAX", "0")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    rng = np.random.default_rng(27)
+    for count in (1, 33, 515):
+        lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
+        lv1[0, :N] = 0
+        lv1[-1, :N] = 0xFFFFFFFF
+        got = eng.batch_identity_key_switch(lv1)
+        exp = O.batch_identity_key_switching(ck, lv1) if hasattr(O, "batch_identity_key_switching") else \
+            np.stack([O.identity_key_switching(ck, x) for x in lv1])
+        assert np.array_equal(got, exp), (setname, env, count)
+    eng.close()
+
+
 def test_blind_rotate_bit_exact(O, eng128, keys128):
     sk, ck = keys128
     cts = sk.encrypt_bool(np.array([1, 0, 1, 1, 0], bool), 27)
