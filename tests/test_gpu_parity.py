@@ -289,6 +289,35 @@ def test_pbs_uint4(O, keys_uint4):
         assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 22)
 
 
+# SECURITY_UINT5 is run at m = 16: with N fixed at 1024 (params.rs:264-289 keeps the 1024-coefficient ring) the
+# rounding of 1071 mask words to 2N positions alone mis-decodes ~5 % of m = 32 messages, on the CPU path too.
+@pytest.mark.parametrize("setname,m", [("SECURITY_UINT2", 4), ("SECURITY_UINT3", 8), ("SECURITY_UINT5", 16)])
+def test_pbs_other_uint_sets(O, setname, m):
+    """The reference's other message-space sets (src/params.rs:177-289): wider key-switch bases (16, 64)
+    and n up to 1071, through LutBootstrap with the message modulus of the set; decrypted messages equal
+    f(x) and equal the CPU path's, phases agree to well under a message step."""
+    import rs_tfhe_amd as R
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    rng = np.random.default_rng(33)
+    msgs = np.concatenate([np.arange(m), rng.integers(0, m, 8)])
+    cts = sk.encrypt_lwe_message(msgs, m, 61)
+    for f in (lambda x: x % m, lambda x: (3 * x + 1) % m):
+        lut = R.lut.Generator(m).generate_lookup_table(f)
+        out = R.LutBootstrap().bootstrap_lut(cts, lut, pk)
+        cpu = O.batch_bootstrap(ck, cts, testvec=lut.poly)
+        want = np.array([f(int(x)) for x in msgs])
+        assert np.array_equal(sk.decrypt_lwe_message(cpu, m), want)
+        assert np.array_equal(sk.decrypt_lwe_message(out, m), want)
+        # not bit-comparable (bgbit >= 18: one f64 LSB flips a digit and the two runs become two
+        # different valid noise realisations); they must agree to 1/8 of a message step
+        assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 32) // (2 * m) // 8
+
+
 def test_xor_and_mux_80bit(O, keys80):
     """BASELINE config 5 parameter set (n = 550, t = 7)."""
     import rs_tfhe_amd as R
