@@ -85,6 +85,8 @@ def broadcast_cloud_key(cloud_key_or_none, params, src: int = 0):
     from .params import N
 
     rank = dist.get_rank()
+    # RCCL moves device memory only: stage through this rank's GPU under the "nccl" backend
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     shapes = {
         "bootstrapping_key": ((params.n, 2 * params.l, 2, N), torch.float64),
         "key_switching_key": ((N, params.iks_t, params.base, params.n + 1), torch.int32),
@@ -97,10 +99,13 @@ def broadcast_cloud_key(cloud_key_or_none, params, src: int = 0):
             t = torch.from_numpy(arr.view(np.int32) if dt == torch.int32 else arr).reshape(shape).clone()
         else:
             t = torch.empty(shape, dtype=dt)
+        t = t.to(dev)
         dist.broadcast(t, src=src)
+        t = t.cpu()
         fields[name] = t.numpy().view(np.uint32) if dt == torch.int32 else t.numpy()
-    off = torch.tensor([int(cloud_key_or_none.decomposition_offset) if rank == src else 0], dtype=torch.int64)
+    off = torch.tensor([int(cloud_key_or_none.decomposition_offset) if rank == src else 0], dtype=torch.int64).to(dev)
     dist.broadcast(off, src=src)
+    off = off.cpu()
     return CloudKey(params, fields["bootstrapping_key"], fields["key_switching_key"], int(off.item()),
                     fields["blind_rotate_testvec"])
 

@@ -750,3 +750,54 @@ def test_calls_on_different_streams_share_one_context(O, eng128, keys128):
         assert np.array_equal(sk.decrypt_bool(g), w)
     for g, gate, (_, _, ca, cb) in zip(got, (O.GATE_NAND, O.GATE_XOR, O.GATE_OR), sets):
         assert np.array_equal(g[:16], O.batch_gate(ck, gate, ca[:16], cb[:16]))
+
+
+def test_rccl_backend_single_rank(O, keys128):
+    """The one-process-per-GPU plumbing under the real "nccl" (= RCCL) backend, world size 1 (the
+    box has one GPU): key replication through device memory, scatter / sharded gate / gather on
+    device tensors, barrier and the max-over-ranks reduction bench.py uses."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd import distributed as D
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        rep = D.broadcast_cloud_key(pk, pk.params, src=0)
+        assert np.array_equal(rep.bootstrapping_key, pk.bootstrapping_key)
+        assert np.array_equal(rep.key_switching_key, pk.key_switching_key)
+        assert rep.decomposition_offset == pk.decomposition_offset
+        eng = R.Engine(pk.params, 0)
+        eng.load_cloud_key(rep)
+        A = np.array([0, 0, 1, 1, 1, 0, 1], bool)
+        B = np.array([0, 1, 0, 1, 1, 1, 0], bool)
+        ca, cb = sk.encrypt_bool(A, 3300), sk.encrypt_bool(B, 3301)
+        fa = torch.from_numpy(ca.view(np.int32)).to(dev)
+        fb = torch.from_numpy(cb.view(np.int32)).to(dev)
+        sa = D.scatter_batch(fa, len(A), 701, src=0, device=dev)
+        sb = D.scatter_batch(fb, len(A), 701, src=0, device=dev)
+        so = torch.empty_like(sa)
+        D.sharded_batch_gate(eng, O.GATE_NAND, sa, sb, so)
+        full = D.gather_batch(so, len(A), 701, dst=0, device=dev)
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        assert float(t) == 1.5
+        got = full.cpu().numpy().view(np.uint32)
+        assert np.array_equal(got, O.batch_gate(ck, O.GATE_NAND, ca, cb))
+        assert np.array_equal(sk.decrypt_bool(got), ~(A & B))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
