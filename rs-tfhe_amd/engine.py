@@ -53,7 +53,7 @@ class Engine:
             msg = self._lib.tfhe_hip_last_error(None)
             raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._ctx = ctx
-        self._key_id = None
+        self._key = None  # the CloudKey object currently loaded (held, so identity cannot be recycled)
 
     # -- lifetime -------------------------------------------------------------
     def close(self) -> None:
@@ -94,7 +94,7 @@ class Engine:
                 self._ctx, _ptr(bsk), _ptr(ksk), C.c_uint32(int(cloud_key.decomposition_offset)), _ptr(tv)
             )
         )
-        self._key_id = id(cloud_key)
+        self._key = cloud_key
 
     def gen_cloud_key(self, key_lv0, key_lv1, seed: int, alpha_ksk=None, alpha_bsk=None) -> None:
         """CloudKey::new(&secret_key) (src/key.rs:59-66) on the GPU, straight into this context."""
@@ -110,7 +110,7 @@ class Engine:
                 C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
             )
         )
-        self._key_id = ("generated", seed)
+        self._key = ("generated", seed)
 
     def export_cloud_key(self):
         """The context's key back as a CloudKey in the reference layouts."""
@@ -125,7 +125,7 @@ class Engine:
         return CloudKey(p, bsk, ksk, int(off.value), tv)
 
     def ensure_key(self, cloud_key) -> None:
-        if self._key_id != id(cloud_key):
+        if self._key is not cloud_key:
             self.load_cloud_key(cloud_key)
 
     # -- batched hot path, host arrays -----------------------------------------
@@ -160,8 +160,8 @@ class Engine:
         if testvec is not None:
             tv = _u32(testvec)
             per_ct = int(tv.ndim == 3)
-            if per_ct and tv.shape[0] != len(cts):
-                raise ValueError("per-ciphertext test vectors: wrong count")
+            if tv.size != (len(cts) if per_ct else 1) * 2 * N:
+                raise ValueError("test vector must be [2][N], or [count][2][N] for per-ciphertext tables")
         self._chk(
             self._lib.tfhe_hip_batch_bootstrap(self._ctx, _ptr(cts), _ptr(tv), per_ct, int(keyswitch), _ptr(out), len(cts))
         )
@@ -171,11 +171,15 @@ class Engine:
         cts = self._cts(cts)
         out = np.empty((len(cts), 2, N), np.uint32)
         tv = _u32(testvec) if testvec is not None else None
+        if tv is not None and tv.size != 2 * N:
+            raise ValueError("test vector must be [2][N]")
         self._chk(self._lib.tfhe_hip_batch_blind_rotate(self._ctx, _ptr(cts), _ptr(tv), _ptr(out), len(cts)))
         return out
 
     def batch_mux(self, a, b, c, naive: bool) -> np.ndarray:
         a, b, c = self._cts(a), self._cts(b), self._cts(c)
+        if b.shape != a.shape or c.shape != a.shape:
+            raise ValueError("operand batches differ in shape")
         out = np.empty_like(a)
         self._chk(self._lib.tfhe_hip_batch_mux(self._ctx, int(naive), _ptr(a), _ptr(b), _ptr(c), _ptr(out), len(a)))
         return out
@@ -184,6 +188,8 @@ class Engine:
     def batch_external_product(self, trlwe, bsk_index) -> np.ndarray:
         trlwe = _u32(trlwe).reshape(-1, 2, N)
         idx = np.ascontiguousarray(bsk_index, dtype=np.int32).reshape(-1)
+        if len(idx) != len(trlwe):
+            raise ValueError("one bootstrapping-key index per TRLWE sample")
         out = np.empty_like(trlwe)
         self._chk(self._lib.tfhe_hip_batch_external_product(self._ctx, _ptr(trlwe), _ptr(idx), _ptr(out), len(trlwe)))
         return out
@@ -214,6 +220,8 @@ class Engine:
 
     def batch_poly_mul(self, a, b) -> np.ndarray:
         a, b = _u32(a).reshape(-1, N), _u32(b).reshape(-1, N)
+        if b.shape != a.shape:
+            raise ValueError("operand batches differ in shape")
         out = np.empty_like(a)
         self._chk(self._lib.tfhe_hip_batch_poly_mul(self._ctx, _ptr(out), _ptr(a), _ptr(b), len(a)))
         return out
@@ -229,8 +237,21 @@ class Engine:
         # context's own stream", so name the null stream explicitly: hipStreamLegacy == (hipStream_t)1
         return C.c_void_p(stream.cuda_stream or 1)
 
+    def _dev_batch(self, *tensors, width=None) -> int:
+        """All tensors are [count][width] on this engine's GPU; returns count."""
+        width = self.params.n + 1 if width is None else width
+        first = tensors[0]
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dim() != 2 or t.shape[1] != width or t.shape[0] != first.shape[0]:
+                raise ValueError(f"device tensors must all be [count][{width}]")
+            if t.device.index != self.device:
+                raise ValueError(f"device tensor lives on {t.device}, the engine on cuda:{self.device}")
+        return first.shape[0]
+
     def batch_gate_dev(self, gate: int, a, b, out, stream=None) -> None:
-        count = a.shape[0]
+        count = self._dev_batch(a, b, out)
         self._chk(
             self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream))
         )
@@ -239,30 +260,40 @@ class Engine:
         """gates: uint8 CUDA tensor [count]; a, b, out: int32 CUDA tensors [count][n+1]."""
         if not gates.is_cuda or gates.element_size() != 1 or not gates.is_contiguous():
             raise ValueError("gates must be a contiguous uint8 CUDA tensor")
+        count = self._dev_batch(a, b, out)
+        if gates.numel() != count:
+            raise ValueError("one gate code per ciphertext")
         self._chk(
             self._lib.tfhe_hip_batch_gates_mixed_dev(
-                self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), a.shape[0], self._stream_ptr(stream)
+                self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream)
             )
         )
 
     def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:
+        count = self._dev_batch(cts, out)
+        if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
+            raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
         self._chk(
             self._lib.tfhe_hip_batch_bootstrap_dev(
-                self._ctx, _tptr(cts), _tptr(testvec), int(per_ct), int(keyswitch), _tptr(out), cts.shape[0], self._stream_ptr(stream)
+                self._ctx, _tptr(cts), _tptr(testvec), int(per_ct), int(keyswitch), _tptr(out), count, self._stream_ptr(stream)
             )
         )
 
     def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None) -> None:
+        count = self._dev_batch(cts)
+        if out_trlwe.numel() != count * 2 * N or (testvec is not None and testvec.numel() != 2 * N):
+            raise ValueError("out_trlwe must be [count][2][N], testvec [2][N]")
         self._chk(
             self._lib.tfhe_hip_batch_blind_rotate_dev(
-                self._ctx, _tptr(cts), _tptr(testvec), _tptr(out_trlwe), cts.shape[0], self._stream_ptr(stream)
+                self._ctx, _tptr(cts), _tptr(testvec), _tptr(out_trlwe), count, self._stream_ptr(stream)
             )
         )
 
     def batch_mux_dev(self, a, b, c, out, naive: bool, stream=None) -> None:
+        count = self._dev_batch(a, b, c, out)
         self._chk(
             self._lib.tfhe_hip_batch_mux_dev(
-                self._ctx, int(naive), _tptr(a), _tptr(b), _tptr(c), _tptr(out), a.shape[0], self._stream_ptr(stream)
+                self._ctx, int(naive), _tptr(a), _tptr(b), _tptr(c), _tptr(out), count, self._stream_ptr(stream)
             )
         )
 

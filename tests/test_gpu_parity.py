@@ -679,6 +679,25 @@ def test_edge_cases_and_errors(O, eng128, keys128):
     # COPY ignores the second operand
     ct = sk.encrypt_bool([1, 0], 3)
     assert np.array_equal(eng128.batch_gate(O.GATE_COPY, ct, None), O.batch_bootstrap(ck, ct))
+    # shape mistakes are caught on the host, before any pointer reaches the library
+    import torch
+
+    with pytest.raises(ValueError):
+        eng128.batch_gate(O.GATE_NAND, ct, ct[:1])
+    with pytest.raises(ValueError):
+        eng128.batch_bootstrap(ct, testvec=np.zeros((2, 512), np.uint32))
+    with pytest.raises(ValueError):
+        eng128.batch_mux(ct, ct, ct[:1], naive=True)
+    dev = torch.device("cuda:0")
+    ta = torch.zeros((4, 701), dtype=torch.int32, device=dev)
+    with pytest.raises(ValueError):
+        eng128.batch_gate_dev(O.GATE_NAND, ta, ta[:3].contiguous(), torch.empty_like(ta))
+    with pytest.raises(ValueError):
+        eng128.batch_gate_dev(O.GATE_NAND, ta, ta, torch.empty((4, 700), dtype=torch.int32, device=dev))
+    with pytest.raises(ValueError):
+        eng128.batch_gate_dev(O.GATE_NAND, ta.cpu(), ta, torch.empty_like(ta))
+    with pytest.raises(ValueError):
+        eng128.batch_blind_rotate_dev(ta, torch.empty((4, 2, 512), dtype=torch.int32, device=dev))
 
 
 # ---- device-resident path + full-size properties -------------------------------------------------
