@@ -376,6 +376,22 @@ class CloudKey:
             C.c_uint64(seed * 2 + 2), C.byref(cp), _p(sk.key_lv0), _p(sk.key_lv1), _p(self.key_switching_key)
         )
 
+    @classmethod
+    def from_arrays(cls, params: Params, bootstrapping_key, key_switching_key, decomposition_offset,
+                    blind_rotate_testvec) -> "CloudKey":
+        """Wrap key material produced elsewhere (e.g. exported from the GPU key generator) so the CPU
+        path can be run under the very same key."""
+        self = cls.__new__(cls)
+        self.params = params
+        self.decomposition_offset = int(decomposition_offset)
+        self.blind_rotate_testvec = np.ascontiguousarray(blind_rotate_testvec, np.uint32).reshape(2, N)
+        self.bootstrapping_key = np.ascontiguousarray(bootstrapping_key, np.float64).reshape(
+            params.n, 2 * params.l, 2, N)
+        self.bootstrapping_key_time = None
+        self.key_switching_key = np.ascontiguousarray(key_switching_key, np.uint32).reshape(
+            N, params.t, params.base, params.n + 1)
+        return self
+
     def c(self) -> _CloudKey:
         ck = _CloudKey()
         ck.P = self.params.c()

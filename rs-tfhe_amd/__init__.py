@@ -1,14 +1,15 @@
 """rs-tfhe_amd: MI355X-native (gfx950 HIP) engine for the gate-bootstrapping hot
 path of thedonutfactory/rs-tfhe, behind the reference's own API surface.
 
-    from rs_tfhe_amd import gates, key, params, bootstrap, lut
+    from rs_tfhe_amd import gates, key, params, bootstrap, lut, client
 
 The compute is entirely in rs-tfhe_amd/libtfhe_hip.so (C ABI in
 include/tfhe_hip.h); importing this package never falls back to a CPU path.
 """
-from . import _capi, bootstrap, circuit, distributed, engine, gates, key, lut, params  # noqa: F401
+from . import _capi, bootstrap, circuit, client, distributed, engine, gates, key, lut, params  # noqa: F401
 from .bootstrap import Bootstrap, HipBootstrap, LutBootstrap, default_bootstrap  # noqa: F401
 from .circuit import Circuit  # noqa: F401
+from .client import SecretKey  # noqa: F401
 from .engine import Engine  # noqa: F401
 from .gates import Gates  # noqa: F401
 from .key import CloudKey  # noqa: F401
@@ -16,4 +17,4 @@ from .params import SECURITY_128_BIT, SecurityParams  # noqa: F401
 
 __all__ = ["Engine", "Gates", "CloudKey", "Bootstrap", "HipBootstrap", "LutBootstrap", "default_bootstrap",
            "SecurityParams", "SECURITY_128_BIT", "gates", "key", "params", "bootstrap", "lut", "engine",
-           "distributed", "circuit", "Circuit"]
+           "distributed", "circuit", "Circuit", "client", "SecretKey"]

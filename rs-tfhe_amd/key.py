@@ -1,8 +1,8 @@
 """CloudKey: the evaluation key bundle of the reference (src/key.rs:51-56).
 
-Key *generation* is client-side work that needs the secret key and is out of
-scope for the GPU engine; this class only carries the
-four fields the hot path borrows, in the flat layouts of include/tfhe_hip.h.
+This class carries the four fields the hot path borrows, in the flat layouts of
+include/tfhe_hip.h.  `CloudKey.new(secret_key)` (src/key.rs:59-66) generates them on
+the GPU (client.SecretKey.cloud_key -> tfhe_hip_gen_cloud_key).
 """
 from __future__ import annotations
 
@@ -19,6 +19,11 @@ def gen_testvec() -> np.ndarray:
 
 
 class CloudKey:
+    @classmethod
+    def new(cls, secret_key, seed: int = 0, device: int = 0) -> "CloudKey":
+        """CloudKey::new(&secret_key), src/key.rs:59-66."""
+        return secret_key.cloud_key(seed, device)
+
     def __init__(self, params: SecurityParams, bootstrapping_key, key_switching_key,
                  decomposition_offset=None, blind_rotate_testvec=None):
         self.params = params

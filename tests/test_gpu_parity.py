@@ -820,3 +820,33 @@ def test_rccl_backend_single_rank(O, keys128):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_client_keygen_encrypt_gate_decrypt_round_trip(O):
+    """The reference's README flow with the product package alone: SecretKey::new, CloudKey::new,
+    encrypt, a gate, decrypt (README.md:60-80 of the reference) -- then the same ciphertexts through
+    the CPU path under the exported key must give the same words."""
+    import rs_tfhe_amd as R
+
+    P = R.params.SECURITY_128_BIT
+    sk = R.SecretKey.new(P, seed=41)
+    ck = R.CloudKey.new(sk, seed=42)
+    A = np.array([0, 0, 1, 1], bool)
+    B = np.array([0, 1, 0, 1], bool)
+    ca, cb = sk.encrypt_bool(A, seed=43), sk.encrypt_bool(B, seed=44)
+    g = R.Gates()
+    out = np.stack([g.nand(x, y, ck) for x, y in zip(ca, cb)])
+    assert np.array_equal(sk.decrypt_bool(out), ~(A & B))
+    assert np.array_equal(sk.decrypt_bool(R.gates.batch_xor(ca, cb, ck)), A ^ B)
+    # CPU path under the very same (GPU-generated, exported) key
+    ock = O.CloudKey.from_arrays(O.SECURITY_128_BIT, ck.bootstrapping_key, ck.key_switching_key,
+                                 ck.decomposition_offset, ck.blind_rotate_testvec)
+    assert np.array_equal(out, O.batch_gate(ock, O.GATE_NAND, ca, cb))
+    # programmable bootstrap with the client's message encoding
+    P4 = R.params.SECURITY_UINT4
+    sk4 = R.SecretKey.new(P4, seed=45)
+    ck4 = R.CloudKey.new(sk4, seed=46)
+    msgs = np.arange(16)
+    lut = R.lut.Generator(16).generate_lookup_table(lambda x: (5 * x + 3) % 16)
+    res = R.LutBootstrap().bootstrap_lut(sk4.encrypt_lwe_message(msgs, 16, seed=47), lut, ck4)
+    assert np.array_equal(sk4.decrypt_lwe_message(res, 16), (5 * msgs + 3) % 16)
