@@ -21,11 +21,13 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <random>
 #include <utility>
 #include <vector>
 
@@ -116,7 +118,10 @@ class Engine {
 
   void ensure_key(const CloudKey &ck) {
     std::lock_guard<std::mutex> lk(mu_);
-    if (loaded_ == &ck) return;  // `&CloudKey` identity, as the reference borrows it
+    // `&CloudKey` identity, as the reference borrows it -- plus a content sample, because an address
+    // can be reused by a different key once the first one is gone
+    const uint64_t fp = fingerprint(ck);
+    if (loaded_ == &ck && loaded_fp_ == fp) return;
     const SecurityParams &p = params_;
     if (ck.bootstrapping_key.size() != (size_t)p.n * 2 * p.l * 2 * N ||
         ck.key_switching_key.size() != N * (size_t)p.iks_t * p.base() * (p.n + 1))
@@ -124,6 +129,12 @@ class Engine {
     check(tfhe_hip_load_cloud_key(ctx_, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
                                   ck.decomposition_offset, ck.blind_rotate_testvec.a.data()));
     loaded_ = &ck;
+    loaded_fp_ = fp;
+  }
+  // the context now holds a key that no CloudKey object describes (tfhe_hip_gen_cloud_key)
+  void forget_key() {
+    std::lock_guard<std::mutex> lk(mu_);
+    loaded_ = nullptr;
   }
   void check(int rc) const {
     if (rc != TFHE_HIP_OK) throw std::runtime_error(std::string("tfhe_hip: ") + tfhe_hip_last_error(ctx_));
@@ -131,24 +142,103 @@ class Engine {
   tfhe_hip_ctx *ctx() const { return ctx_; }
   const SecurityParams &params() const { return params_; }
 
-  static Engine &for_key(const CloudKey &ck, int device = 0) {
+  static Engine &for_params(const SecurityParams &p, int device = 0) {
     static std::mutex mu;
     static std::vector<std::unique_ptr<Engine>> engines;
     std::lock_guard<std::mutex> lk(mu);
     for (auto &e : engines)
-      if (e->params_ == ck.params && e->device_ == device) return *e;
-    engines.emplace_back(new Engine(ck.params, device));
+      if (e->params_ == p && e->device_ == device) return *e;
+    engines.emplace_back(new Engine(p, device));
     engines.back()->device_ = device;
     return *engines.back();
   }
+  static Engine &for_key(const CloudKey &ck, int device = 0) { return for_params(ck.params, device); }
 
  private:
+  static uint64_t fingerprint(const CloudKey &ck) {  // 64 evenly spaced words of each key + sizes
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ ck.decomposition_offset;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 0x100000001B3ull; };
+    const size_t nk = ck.key_switching_key.size(), nb = ck.bootstrapping_key.size();
+    for (size_t i = 0; i < 64 && nk; ++i) mix(ck.key_switching_key[(nk - 1) - (nk - 1) * i / 64]);
+    for (size_t i = 0; i < 64 && nb; ++i) {
+      uint64_t bits;
+      std::memcpy(&bits, &ck.bootstrapping_key[(nb - 1) * i / 64], sizeof bits);
+      mix(bits);
+    }
+    mix(nk);
+    mix(nb);
+    return h;
+  }
+  uint64_t loaded_fp_ = 0;
   SecurityParams params_;
   tfhe_hip_ctx *ctx_ = nullptr;
   const CloudKey *loaded_ = nullptr;
   int device_ = 0;
   std::mutex mu_;
 };
+
+// ---- client side: src/key.rs:21-48, src/tlwe.rs:37-126, src/key.rs:59-66 ---------------------------
+// The reference draws from an unseeded thread_rng; here the caller owns a seeded std::mt19937_64.
+struct SecretKey {
+  SecurityParams params = DEFAULT_SECURITY;
+  std::vector<Torus> key_lv0, key_lv1;  // uniform bits, n and N of them
+  static SecretKey generate(const SecurityParams &p, uint64_t seed) {  // SecretKey::new
+    SecretKey sk;
+    sk.params = p;
+    std::mt19937_64 rng(seed);
+    sk.key_lv0.resize((size_t)p.n);
+    sk.key_lv1.resize(N);
+    for (auto &b : sk.key_lv0) b = (Torus)(rng() & 1u);
+    for (auto &b : sk.key_lv1) b = (Torus)(rng() & 1u);
+    return sk;
+  }
+};
+
+namespace tlwe {
+inline Torus inner_product(const Ciphertext &c, const std::vector<Torus> &key) {
+  Torus ip = 0;
+  for (size_t i = 0; i < key.size(); ++i) ip += c.p[i] * key[i];  // wrapping, tlwe.rs:42-46
+  return ip;
+}
+// tlwe.rs:37-53: a uniform, b = <a, s> + f64_to_torus(p) + f64_to_torus(N(0, alpha))
+inline Ciphertext encrypt_f64(double p, double alpha, const std::vector<Torus> &key, std::mt19937_64 &rng) {
+  Ciphertext c((int)key.size());
+  for (size_t i = 0; i < key.size(); ++i) c.p[i] = (Torus)rng();
+  std::normal_distribution<double> noise(0.0, alpha);
+  c.b_mut() = inner_product(c, key) + f64_to_torus(p) + (alpha > 0 ? f64_to_torus(noise(rng)) : 0u);
+  return c;
+}
+inline Ciphertext encrypt_bool(bool b, double alpha, const std::vector<Torus> &key, std::mt19937_64 &rng) {  // :55-58
+  return encrypt_f64(b ? 0.125 : -0.125, alpha, key, rng);
+}
+inline Torus phase(const Ciphertext &c, const std::vector<Torus> &key) { return c.b() - inner_product(c, key); }
+inline bool decrypt_bool(const Ciphertext &c, const std::vector<Torus> &key) {  // :60-68
+  return (int32_t)phase(c, key) >= 0;
+}
+inline Ciphertext encrypt_lwe_message(size_t message, size_t modulus, double alpha, const std::vector<Torus> &key,
+                                      std::mt19937_64 &rng) {  // :84-98
+  return encrypt_f64((double)(message % modulus) * (1.0 / (2.0 * (double)modulus)), alpha, key, rng);
+}
+inline size_t decrypt_lwe_message(const Ciphertext &c, size_t modulus, const std::vector<Torus> &key) {  // :111-126
+  const double scale = 1.0 / (2.0 * (double)modulus);
+  return (size_t)(torus_to_f64(phase(c, key)) / scale + 0.5) % modulus;
+}
+}  // namespace tlwe
+
+// CloudKey::new(&secret_key) (key.rs:59-66): generated on the GPU, returned in the reference layouts
+inline CloudKey generate_cloud_key(const SecretKey &sk, uint64_t seed, int device = 0) {
+  const SecurityParams &p = sk.params;
+  Engine &e = Engine::for_params(p, device);
+  e.forget_key();
+  e.check(tfhe_hip_gen_cloud_key(e.ctx(), sk.key_lv0.data(), sk.key_lv1.data(), p.alpha_lv0, p.alpha_lv1, seed));
+  CloudKey ck;
+  ck.params = p;
+  ck.bootstrapping_key.resize((size_t)p.n * 2 * p.l * 2 * N);
+  ck.key_switching_key.resize(N * (size_t)p.iks_t * p.base() * (p.n + 1));
+  e.check(tfhe_hip_export_cloud_key(e.ctx(), ck.bootstrapping_key.data(), ck.key_switching_key.data(),
+                                    &ck.decomposition_offset, ck.blind_rotate_testvec.a.data()));
+  return ck;
+}
 
 namespace detail {
 inline std::vector<Torus> flatten(const std::vector<Ciphertext> &v, int n) {

@@ -37,29 +37,29 @@ static int failures = 0;
     }                                                 \
   } while (0)
 
-struct SecretKey {  // key::SecretKey (src/key.rs:21-49)
+struct OracleSecretKey {  // key::SecretKey (src/key.rs:21-49), filled by the oracle's generator
   std::vector<Torus> key_lv0, key_lv1;
 };
 
 static uint64_t g_seed = 1;
-static Ciphertext encrypt_bool(bool b, const SecurityParams &P, const SecretKey &sk) {  // tlwe.rs:55-58
+static Ciphertext encrypt_bool(bool b, const SecurityParams &P, const OracleSecretKey &sk) {  // tlwe.rs:55-58
   Ciphertext c(P.n);
   orc_tlwe_encrypt_f64(g_seed++, b ? 0.125 : -0.125, P.alpha_lv0, sk.key_lv0.data(), P.n, c.p.data());
   return c;
 }
-static Ciphertext encrypt_lwe_message(size_t m, size_t modulus, const SecurityParams &P, const SecretKey &sk) {  // tlwe.rs:84-98
+static Ciphertext encrypt_lwe_message(size_t m, size_t modulus, const SecurityParams &P, const OracleSecretKey &sk) {  // tlwe.rs:84-98
   Ciphertext c(P.n);
   orc_tlwe_encrypt_f64(g_seed++, (double)(m % modulus) / (2.0 * modulus), P.alpha_lv0, sk.key_lv0.data(), P.n, c.p.data());
   return c;
 }
-static bool decrypt_bool(const Ciphertext &c, const SecretKey &sk) {
+static bool decrypt_bool(const Ciphertext &c, const OracleSecretKey &sk) {
   return orc_tlwe_decrypt_bool(c.p.data(), sk.key_lv0.data(), c.n()) != 0;
 }
 
 // gates.rs:832-858 `test_gate`
 static void test_gate(const char *name, const std::function<bool(bool, bool)> &expect,
                       const std::function<Ciphertext(const Gates &, const Ciphertext &, const Ciphertext &, const CloudKey &)> &actual,
-                      const SecretKey &key, const CloudKey &cloud_key) {
+                      const OracleSecretKey &key, const CloudKey &cloud_key) {
   Gates gates;
   const bool cases[4][2] = {{true, true}, {true, false}, {false, true}, {false, false}};
   for (auto &tc : cases) {
@@ -74,7 +74,7 @@ int main() {
   orc_init();
   const SecurityParams P = SECURITY_128_BIT;
   orc_params OP{P.n, P.l, P.bgbit, P.basebit, P.iks_t, P.alpha_lv0, P.alpha_lv1};
-  SecretKey key;
+  OracleSecretKey key;
   key.key_lv0.resize(P.n);
   key.key_lv1.resize(N);
   orc_gen_secret_key(99, P.n, key.key_lv0.data(), key.key_lv1.data());
@@ -159,6 +159,37 @@ int main() {
   {
     auto r = trgsw::batch_blind_rotate({encrypt_bool(true, P, key), encrypt_bool(false, P, key)}, cloud_key);
     CHECK(r.size() == 2, "batch_blind_rotate size");
+  }
+  // client side through the header alone (key.rs:21-66, tlwe.rs:37-126): keys, GPU key generation,
+  // encryption, a gate, decryption -- cross-checked against the oracle's decoders on the same words
+  {
+    rs_tfhe::SecretKey sk = rs_tfhe::SecretKey::generate(P, 4242);
+    CHECK(sk.key_lv0.size() == (size_t)P.n && sk.key_lv1.size() == N, "secret key sizes");
+    CloudKey gk = generate_cloud_key(sk, 77);
+    CHECK(gk.decomposition_offset == 0x82080000u, "generated key: decomposition offset");
+    CHECK(gk.blind_rotate_testvec.b[5] == 0x20000000u && gk.blind_rotate_testvec.a[5] == 0, "generated key: test vector");
+    std::mt19937_64 rng(5);
+    Gates g;
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        Ciphertext ca = tlwe::encrypt_bool(a, P.alpha_lv0, sk.key_lv0, rng), cb = tlwe::encrypt_bool(b, P.alpha_lv0, sk.key_lv0, rng);
+        CHECK(tlwe::decrypt_bool(ca, sk.key_lv0) == (bool)a, "fresh encryption decrypts");
+        CHECK(tlwe::decrypt_bool(ca, sk.key_lv0) == (orc_tlwe_decrypt_bool(ca.p.data(), sk.key_lv0.data(), P.n) != 0), "decoders agree");
+        Ciphertext r = g.nand(ca, cb, gk);
+        CHECK(tlwe::decrypt_bool(r, sk.key_lv0) == !(a && b), "nand under a GPU-generated key %d %d", a, b);
+        CHECK(tlwe::decrypt_bool(r, sk.key_lv0) == (orc_tlwe_decrypt_bool(r.p.data(), sk.key_lv0.data(), P.n) != 0), "decoders agree on the result");
+      }
+    for (size_t m = 0; m < 4; ++m) {
+      Ciphertext c = tlwe::encrypt_lwe_message(m + 8, 4, P.alpha_lv0, sk.key_lv0, rng);
+      CHECK(tlwe::decrypt_lwe_message(c, 4, sk.key_lv0) == m, "message round trip %zu", m);
+      CHECK((int)tlwe::decrypt_lwe_message(c, 4, sk.key_lv0) == orc_tlwe_decrypt_lwe_message(c.p.data(), 4, sk.key_lv0.data(), P.n), "message decoders agree");
+    }
+    // a different key object at the same address must not be mistaken for the loaded one
+    CloudKey *slot = new CloudKey(gk);
+    CHECK(tlwe::decrypt_bool(g.nand(tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, rng), tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, rng), *slot), sk.key_lv0) == false, "copy of the key");
+    *slot = cloud_key;  // the oracle-generated key for `key`, same address
+    CHECK(decrypt_bool(g.nand(encrypt_bool(true, P, key), encrypt_bool(false, P, key), *slot), key) == true, "address reuse re-uploads");
+    delete slot;
   }
   std::printf(failures ? "%d FAILURES\n" : "all C++ mirror tests passed (%d failures)\n", failures);
   return failures ? 1 : 0;
