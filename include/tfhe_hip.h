@@ -166,6 +166,29 @@ int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const ui
                                  int per_ct, int keyswitch, uint32_t *out, size_t count,
                                  void *stream);
 
+/* Replaces: the TLWE arithmetic between bootstraps -- Add, Sub, Neg, AddMul, SubMul for &TLWELv0
+ * (src/tlwe.rs:129-214) -- mapped over a batch:  out = ca * a + cb * b  on all n+1 words (wrapping u32),
+ * then out[n] += cconst.  Add = (1, 1, 0), Sub = (1, -1, 0), Neg = (-1, 0, 0) with b = NULL,
+ * AddMul(k) = (1, k, 0), SubMul(k) = (1, -k, 0).  b may be NULL when cb == 0.  out may alias a or b. */
+int tfhe_hip_batch_tlwe_lincomb(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count);
+int tfhe_hip_batch_tlwe_lincomb_dev(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                    const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count,
+                                    void *stream);
+
+/* Replaces: `bootstrap_lut(&(&x + &y), &lut, &cloud_key)` -- a TLWE linear combination fed straight
+ * into a (programmable) bootstrap, the shape of every step of the reference's LUT arithmetic
+ * (examples/lut_add_two_numbers.rs:124-158, examples/lut_arithmetic_demo.rs) and, with the default
+ * test vector, of every gate (src/gates.rs:54-150).  The combination is computed in the prologue of
+ * the blind-rotation kernel; arguments as in tfhe_hip_batch_tlwe_lincomb and tfhe_hip_batch_bootstrap. */
+int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                     const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
+                                     int per_ct, int keyswitch, uint32_t *out, size_t count);
+int tfhe_hip_batch_lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                         const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
+                                         int per_ct, int keyswitch, uint32_t *out, size_t count,
+                                         void *stream);
+
 /* Replaces: trgsw::batch_blind_rotate[_with_railgun] (src/trgsw.rs:289-305),
  * trgsw::blind_rotate (:198-226) and blind_rotate_with_testvec (:242-274).
  * in [count][n+1]; testvec NULL or [2][N]; out_trlwe [count][2][N]. */

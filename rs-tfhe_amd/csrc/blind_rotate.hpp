@@ -437,6 +437,19 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
   }
 }
 
+// ---- TLWE arithmetic between bootstraps (tlwe.rs:129-214): out = ca*a + cb*b, out[n] += cconst -------
+// Pure streaming integer work: one word per thread, coalesced, HBM-bound.
+__global__ void k_tlwe_lincomb(uint32_t ca, const uint32_t *__restrict__ a, uint32_t cb,
+                               const uint32_t *__restrict__ b, uint32_t cconst, uint32_t *__restrict__ out,
+                               uint32_t width, size_t total) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  uint32_t v = ca * a[idx];
+  if (b) v += cb * b[idx];
+  if (idx % width == width - 1) v += cconst;
+  out[idx] = v;
+}
+
 // ---- stage kernels (parity tests; same device code) --------------------------
 
 // external_product_with_fft (trgsw.rs:77-116): out = BSK[idx] (x) in

@@ -331,6 +331,28 @@ int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec
   return launch_blind_rotate(ctx, s, in, nullptr, gp, testvec, per_ct, count, nullptr, nullptr, out);
 }
 
+int lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, GatePrep gp, const uint32_t *a, const uint32_t *b,
+                          const uint32_t *testvec, int per_ct, int keyswitch, uint32_t *out, size_t count,
+                          hipStream_t s) {
+  if (keyswitch) {
+    CHK(claim_scratch(ctx, s));
+    CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+    CHK(launch_blind_rotate(ctx, s, a, b, gp, testvec, per_ct, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
+    return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
+  }
+  return launch_blind_rotate(ctx, s, a, b, gp, testvec, per_ct, count, nullptr, nullptr, out);
+}
+
+int lincomb_dev(tfhe_hip_ctx *ctx, GatePrep gp, const uint32_t *a, const uint32_t *b, uint32_t *out, size_t count,
+                hipStream_t s) {
+  if (count == 0) return TFHE_HIP_OK;
+  const size_t total = count * (size_t)(ctx->P.n + 1);
+  hipLaunchKernelGGL(k_tlwe_lincomb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gp.ca, a,
+                     gp.cb, gp.cb ? b : nullptr, gp.cconst, out, (uint32_t)(ctx->P.n + 1), total);
+  HIPCHK(ctx, hipGetLastError());
+  return TFHE_HIP_OK;
+}
+
 int mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c,
             uint32_t *out, size_t count, hipStream_t s) {
   const size_t ctb = count * (size_t)(ctx->P.n + 1) * 4;
@@ -638,6 +660,29 @@ int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const ui
   return bootstrap_dev(ctx, in, testvec, per_ct, keyswitch, out, count, pick(ctx, stream));
 }
 
+int tfhe_hip_batch_tlwe_lincomb_dev(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                    const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count,
+                                    void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count && (!a || !out || (cb && !b))) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return lincomb_dev(ctx, GatePrep{ca, cb, cconst}, a, b, out, count, pick(ctx, stream));
+}
+
+int tfhe_hip_batch_lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                         const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
+                                         int per_ct, int keyswitch, uint32_t *out, size_t count,
+                                         void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count && (!a || !out || (cb && !b))) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return lincomb_bootstrap_dev(ctx, GatePrep{ca, cb, cconst}, a, cb ? b : nullptr, testvec, per_ct, keyswitch, out,
+                               count, pick(ctx, stream));
+}
+
 int tfhe_hip_batch_blind_rotate_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                     uint32_t *out_trlwe, size_t count, void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
@@ -718,6 +763,46 @@ int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32
   }
   CHK(ensure(ctx, ctx->h_out, bytes));
   CHK(bootstrap_dev(ctx, (uint32_t *)ctx->h_a.p, d_tv, per_ct, keyswitch, (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_tlwe_lincomb(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (count == 0) return TFHE_HIP_OK;
+  if (!a || !out || (cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  if (cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(lincomb_dev(ctx, GatePrep{ca, cb, cconst}, (const uint32_t *)ctx->h_a.p, (const uint32_t *)ctx->h_b.p,
+                  (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                     const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
+                                     int per_ct, int keyswitch, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!a || !out || (cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  if (cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  const uint32_t *d_tv = nullptr;
+  if (testvec) {
+    CHK(to_dev(ctx, ctx->h_tv, testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4));
+    d_tv = (const uint32_t *)ctx->h_tv.p;
+  }
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(lincomb_bootstrap_dev(ctx, GatePrep{ca, cb, cconst}, (const uint32_t *)ctx->h_a.p,
+                            cb ? (const uint32_t *)ctx->h_b.p : nullptr, d_tv, per_ct, keyswitch,
+                            (uint32_t *)ctx->h_out.p, count, ctx->stream));
   return to_host(ctx, out, ctx->h_out, bytes);
 }
 

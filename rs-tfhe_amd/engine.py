@@ -167,6 +167,38 @@ class Engine:
         )
         return out
 
+    def batch_tlwe_lincomb(self, ca: int, a, cb: int = 0, b=None, cconst: int = 0) -> np.ndarray:
+        """ca*a + cb*b on every word, + cconst on the body: TLWE Add / Sub / Neg / AddMul / SubMul
+        (src/tlwe.rs:129-214)."""
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if (cb & 0xFFFFFFFF) and (bb is None or bb.shape != a.shape):
+            raise ValueError("second operand missing or of a different shape")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_tlwe_lincomb(
+            self._ctx, ca & 0xFFFFFFFF, _ptr(a), cb & 0xFFFFFFFF, _ptr(bb), cconst & 0xFFFFFFFF, _ptr(out), len(a)))
+        return out
+
+    def batch_lincomb_bootstrap(self, ca: int, a, cb: int = 0, b=None, cconst: int = 0, testvec=None,
+                                keyswitch: bool = True) -> np.ndarray:
+        """bootstrap(ca*a + cb*b + cconst) with an optional LookupTable.poly: the combination is formed in
+        the prologue of the blind-rotation kernel (examples/lut_add_two_numbers.rs:124-158)."""
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if (cb & 0xFFFFFFFF) and (bb is None or bb.shape != a.shape):
+            raise ValueError("second operand missing or of a different shape")
+        tv, per_ct = None, 0
+        if testvec is not None:
+            tv = _u32(testvec)
+            per_ct = int(tv.ndim == 3)
+            if tv.size != (len(a) if per_ct else 1) * 2 * N:
+                raise ValueError("test vector must be [2][N], or [count][2][N] for per-ciphertext tables")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_batch_lincomb_bootstrap(
+            self._ctx, ca & 0xFFFFFFFF, _ptr(a), cb & 0xFFFFFFFF, _ptr(bb), cconst & 0xFFFFFFFF, _ptr(tv), per_ct,
+            int(keyswitch), _ptr(out), len(a)))
+        return out
+
     def batch_blind_rotate(self, cts, testvec=None) -> np.ndarray:
         cts = self._cts(cts)
         out = np.empty((len(cts), 2, N), np.uint32)
@@ -278,6 +310,21 @@ class Engine:
                 self._ctx, _tptr(cts), _tptr(testvec), int(per_ct), int(keyswitch), _tptr(out), count, self._stream_ptr(stream)
             )
         )
+
+    def batch_tlwe_lincomb_dev(self, ca: int, a, cb: int, b, cconst: int, out, stream=None) -> None:
+        count = self._dev_batch(a, b, out)
+        self._chk(self._lib.tfhe_hip_batch_tlwe_lincomb_dev(
+            self._ctx, ca & 0xFFFFFFFF, _tptr(a), cb & 0xFFFFFFFF, _tptr(b), cconst & 0xFFFFFFFF, _tptr(out), count,
+            self._stream_ptr(stream)))
+
+    def batch_lincomb_bootstrap_dev(self, ca: int, a, cb: int, b, cconst: int, out, testvec=None,
+                                    per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:
+        count = self._dev_batch(a, b, out)
+        if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
+            raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
+        self._chk(self._lib.tfhe_hip_batch_lincomb_bootstrap_dev(
+            self._ctx, ca & 0xFFFFFFFF, _tptr(a), cb & 0xFFFFFFFF, _tptr(b), cconst & 0xFFFFFFFF, _tptr(testvec),
+            int(per_ct), int(keyswitch), _tptr(out), count, self._stream_ptr(stream)))
 
     def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None) -> None:
         count = self._dev_batch(cts)

@@ -42,8 +42,11 @@ def _cloud_key(ck):
     return ck._product
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def eng128(O, keys128):
+    """The process-wide engine for SECURITY_128_BIT with the oracle-generated key loaded.  Function
+    scope on purpose: other tests load other keys into the same shared engine (ensure_key is a no-op
+    when the key is already the loaded one)."""
     import rs_tfhe_amd as R
 
     sk, ck = keys128
@@ -850,3 +853,95 @@ def test_client_keygen_encrypt_gate_decrypt_round_trip(O):
     lut = R.lut.Generator(16).generate_lookup_table(lambda x: (5 * x + 3) % 16)
     res = R.LutBootstrap().bootstrap_lut(sk4.encrypt_lwe_message(msgs, 16, seed=47), lut, ck4)
     assert np.array_equal(sk4.decrypt_lwe_message(res, 16), (5 * msgs + 3) % 16)
+
+
+def test_tlwe_lincomb_and_fused_bootstrap(O, eng128, keys128):
+    """TLWE Add / Sub / Neg / AddMul / SubMul (tlwe.rs:129-214) word for word, and the fused
+    lincomb + bootstrap against 'combine on the host, then bootstrap' through the CPU path."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    rng = np.random.default_rng(51)
+    a = rng.integers(0, 2**32, (9, 701), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, (9, 701), dtype=np.uint64).astype(np.uint32)
+    M = 0xFFFFFFFF
+    assert np.array_equal(eng128.batch_tlwe_lincomb(1, a, 1, b), a + b)                      # Add
+    assert np.array_equal(eng128.batch_tlwe_lincomb(1, a, -1 & M, b), a - b)                 # Sub
+    assert np.array_equal(eng128.batch_tlwe_lincomb(-1 & M, a), (0 - a).astype(np.uint32))   # Neg
+    assert np.array_equal(eng128.batch_tlwe_lincomb(1, a, 12345, b), a + b * np.uint32(12345))        # AddMul
+    assert np.array_equal(eng128.batch_tlwe_lincomb(1, a, -12345 & M, b), a - b * np.uint32(12345))   # SubMul
+    exp = a + b
+    exp[:, -1] += np.uint32(0x20000000)
+    assert np.array_equal(eng128.batch_tlwe_lincomb(1, a, 1, b, 0x20000000), exp)
+    with pytest.raises(ValueError):
+        eng128.batch_tlwe_lincomb(1, a, 1, None)
+    # fused: every gate is a lincomb + bootstrap with the default test vector
+    A = np.array([0, 0, 1, 1], bool)
+    B = np.array([0, 1, 0, 1], bool)
+    ca, cb = sk.encrypt_bool(A, 5100), sk.encrypt_bool(B, 5101)
+    got = eng128.batch_lincomb_bootstrap(-1 & M, ca, -1 & M, cb, 0x20000000)
+    assert np.array_equal(got, O.batch_gate(ck, O.GATE_NAND, ca, cb))
+    # and with a lookup table: PBS(x + y) == CPU path on the host-side sum
+    msgs_x, msgs_y = np.array([1, 0, 1, 0]), np.array([0, 0, 1, 1])
+    cx, cy = sk.encrypt_lwe_message(msgs_x, 4, 5102), sk.encrypt_lwe_message(msgs_y, 4, 5103)
+    lut = R.lut.Generator(4).generate_lookup_table(lambda v: (3 * v + 1) % 4)
+    fused = eng128.batch_lincomb_bootstrap(1, cx, 1, cy, testvec=lut.poly)
+    assert np.array_equal(fused, O.batch_bootstrap(ck, cx + cy, testvec=lut.poly))
+    assert np.array_equal(sk.decrypt_lwe_message(fused, 4), (3 * (msgs_x + msgs_y) + 1) % 4)
+    assert np.array_equal(eng128.batch_lincomb_bootstrap(1, cx, 1, cy, testvec=lut.poly, keyswitch=False),
+                          O.batch_bootstrap(ck, cx + cy, testvec=lut.poly, keyswitch=False))
+
+
+def test_lut_nibble_adder_circuit(O, eng128, keys128, keys_uint4):
+    """examples/lut_add_two_numbers.rs for a batch of byte pairs: three programmable bootstraps per
+    pair, device-resident.
+    (1) SECURITY_128_BIT, the set the example names: bit-identical to the same composition on the CPU
+        path.  No decrypt claim there: the reference's truncating decomposition (trgsw.rs:144-171, no
+        rounding term in key.rs:78-89) leaves a deterministic error of std 0.0095 on every bootstrap
+        output at bgbit = 6 (measured on the CPU path with all key noise set to zero), more than the
+        1/128 half-step of modulus 32, so ~40 % of nibbles mis-decode on the CPU path too.
+    (2) SECURITY_UINT4 (bgbit = 22): the decrypted bytes are the plain sums."""
+    import torch
+
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd import circuit
+
+    rng = np.random.default_rng(52)
+    a = np.concatenate([[42, 255, 0, 15], rng.integers(0, 256, 28)]).astype(np.int64)
+    b = np.concatenate([[137, 255, 0, 1], rng.integers(0, 256, 28)]).astype(np.int64)
+    gen = R.lut.Generator(32)
+    mod16 = gen.generate_lookup_table(lambda x: x % 16).poly
+    carry = gen.generate_lookup_table(lambda x: 1 if x >= 16 else 0).poly
+    dev = torch.device("cuda:0")
+
+    def run(eng, sk, seed):
+        enc = lambda v, s: sk.encrypt_lwe_message(v, 32, s)  # noqa: E731
+        cts = enc(a & 15, seed), enc(a >> 4, seed + 1), enc(b & 15, seed + 2), enc(b >> 4, seed + 3)
+        t = [torch.from_numpy(x.view(np.int32)).to(dev) for x in cts]
+        out = circuit.lut_add_u8_dev(eng, *t)
+        torch.cuda.synchronize()
+        out = tuple(x.cpu().numpy().view(np.uint32) for x in out)
+        host = circuit.lut_add_u8(eng, *cts)  # the host-array form gives the same words
+        assert all(np.array_equal(x, y) for x, y in zip(out, host))
+        return cts, out
+
+    # (1) word-for-word against the CPU path
+    sk, ck = keys128
+    (al, ah, bl, bh), (sl, sh, cr) = run(eng128, sk, 5200)
+    o_sl = O.batch_bootstrap(ck, al + bl, testvec=mod16)
+    o_cr = O.batch_bootstrap(ck, al + bl, testvec=carry)
+    o_sh = O.batch_bootstrap(ck, ah + bh + o_cr, testvec=mod16)
+    assert np.array_equal(sl, o_sl) and np.array_equal(cr, o_cr) and np.array_equal(sh, o_sh)
+
+    # (2) correct bytes where the parameter set has the precision for modulus 32
+    sk4, ck4 = keys_uint4
+    pk4 = _cloud_key(ck4)
+    eng4 = R.bootstrap.engine_for(pk4.params, 0)
+    eng4.ensure_key(pk4)
+    _, (sl, sh, cr) = run(eng4, sk4, 5300)
+    res = sk4.decrypt_lwe_message(sl, 32) | (sk4.decrypt_lwe_message(sh, 32) << 4)
+    want = (a + b) & 0xFF
+    assert res[0] == 179  # the example's own 42 + 137
+    # n = 820 mask words rounded to 2N positions leave ~2.7 sigma per bootstrap at modulus 32
+    assert (res == want).mean() >= 0.9
+    assert np.array_equal(sk4.decrypt_lwe_message(cr, 32)[res == want], ((a & 15) + (b & 15) >= 16)[res == want])
