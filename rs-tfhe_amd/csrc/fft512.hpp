@@ -245,10 +245,14 @@ __device__ __forceinline__ uint32_t round_to_torus(double x) {
   if (FAST) {
     return (uint32_t)__double2loint(x + 0x1.8p52);
   } else {
-    double r = round(x);
-    double hi = floor(r * 0x1p-32);
-    double lo = fma(hi, -0x1p32, r);
-    return (uint32_t)lo;
+    // |x| < 2^63: peel off the multiple of 2^32 first (exact: power-of-two scaling, round-to-integer,
+    // one fused multiply-add whose result |v| <= 2^31 is representable), then the same trick on v.
+    // Four instructions instead of ten for round / floor / fma / convert.  Like FAST it resolves exact
+    // .5 ties to even instead of away from zero; this path serves bgbit > 10, where the f64 product is
+    // ~2^7 LSB away from the integer product anyway and only phases / messages are comparable.
+    const double q = rint(x * 0x1p-32);
+    const double v = fma(q, -0x1p32, x);
+    return (uint32_t)__double2loint(v + 0x1.8p52);
   }
 }
 
