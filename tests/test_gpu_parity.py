@@ -288,8 +288,9 @@ def test_pbs_uint4(O, keys_uint4):
         want = np.array([f(int(m)) for m in msgs])
         assert np.array_equal(sk.decrypt_lwe_message(out, 16), want)
         assert np.array_equal(sk.decrypt_lwe_message(cpu, 16), want)
-        # phases agree to well under one message step (2^32/32 = 2^27)
-        assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 22)
+        # phases agree to 1/8 of a message step (2^32/32 = 2^27): at bgbit = 22 one f64 LSB flips a
+        # digit, after which the two runs are two different valid noise realisations
+        assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 24)
 
 
 # SECURITY_UINT5 is run at m = 16: with N fixed at 1024 (params.rs:264-289 keeps the 1024-coefficient ring) the
