@@ -101,8 +101,11 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
     // ahead of the FFT they are consumed after, so their latency hides under it.
     const uint32_t row_off = bsk_i_off + (uint32_t)r * (2u * kN2 * 16u);
     f64x2 va[8], vb[8];
+    // with a single digit row per half the row loop disappears and the schedule gets tighter: a
+    // whole a-half in flight spills 12 registers there (measured: 236 ms vs 221 ms at SECURITY_UINT4)
+    constexpr int PA = (L == 1 && kPrefetchA > 6) ? 6 : kPrefetchA;
 #pragma unroll
-    for (int s = 0; s < kPrefetchA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
+    for (int s = 0; s < PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
 #pragma unroll
     for (int s = 0; s < kPrefetchB; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
     double re[8], im[8];
@@ -114,7 +117,7 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
     fft_forward(re, im, tw, tile, lane);
     // the rest of the row is fetched behind the first MACs
 #pragma unroll
-    for (int s = kPrefetchA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
+    for (int s = PA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
 #pragma unroll
     for (int s = kPrefetchB; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
 #pragma unroll
