@@ -336,21 +336,24 @@ __global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__rest
 constexpr int kKsSlSets = 32;      // S: accumulator sets per lane
 constexpr int kKsSlWaves = 4;
 constexpr int kKsSlCts = 4 * kKsSlSets * kKsSlWaves;  // ciphertexts per workgroup (512)
-constexpr int kKsSlStage = 16;      // coefficients whose a_bar words are staged in LDS at a time
+// coefficients whose a_bar words are staged in LDS at a time: 16, or 8 where the ring itself is large
+// (base 64: 3 x 16 KiB), so that two workgroups still share a CU's LDS
+__host__ __device__ __forceinline__ int ks_sliced_stage(int base) { return base >= 64 ? 8 : 16; }
 constexpr int kKsSlSlots = 3;      // ring depth
 
 __host__ __device__ __forceinline__ uint32_t ks_sliced_slot_bytes(int base) {
   return (uint32_t)((base + 15) & ~15) * 256u;  // whole DMA instructions: 4 rows each, 4 waves
 }
 __host__ __device__ __forceinline__ size_t ks_sliced_lds_bytes(int base) {
-  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)kKsSlCts * kKsSlStage * 4;
+  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)kKsSlCts * ks_sliced_stage(base) * 4;
 }
 
+template <int IC>
 __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__restrict__ lv1,  // [count][N+1]
                                                             const unsigned char *__restrict__ ksk,  // engine layout
                                                             int n, int basebit, int t,
                                                             uint32_t *__restrict__ out, size_t count) {
-  constexpr int N = 1024, S = kKsSlSets, IC = kKsSlStage, NS = kKsSlSlots, D = NS - 1;
+  constexpr int N = 1024, S = kKsSlSets, NS = kKsSlSlots, D = NS - 1;
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
   const uint32_t base = 1u << basebit;

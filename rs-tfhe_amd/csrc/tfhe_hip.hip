@@ -266,8 +266,12 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);
   if ((ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024) {
     dim3 sgrid((unsigned)((count + kKsSlCts - 1) / kKsSlCts), (unsigned)((n + 1 + 63) / 64));
-    hipLaunchKernelGGL(k_key_switch_sliced, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
-                       ctx->P.basebit, ctx->P.t, out, count);
+    if (ks_sliced_stage(1 << ctx->P.basebit) == 8)
+      hipLaunchKernelGGL(k_key_switch_sliced<8>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+                         ctx->P.basebit, ctx->P.t, out, count);
+    else
+      hipLaunchKernelGGL(k_key_switch_sliced<16>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+                         ctx->P.basebit, ctx->P.t, out, count);
   } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
     hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
                        ctx->P.t, out, count);

@@ -135,7 +135,8 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32)
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
     ("SECURITY_UINT2", {}),                                  # base 16
-    ("SECURITY_UINT3", {}),                                  # base 64, t = 2
+    ("SECURITY_UINT3", {}),                                  # k_key_switch_sliced, base 64, t = 2
+    ("SECURITY_UINT3", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 64
 ])
 def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, env):
     """Every batch key-switch kernel (the small-batch split kernel switched off), ragged counts that
