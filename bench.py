@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=65536, help="ciphertexts per GPU per step")
     ap.add_argument("--params", default="SECURITY_128_BIT")
     ap.add_argument("--gate", default="nand", help="gate name, or 'pbs' = LutBootstrap::bootstrap_lut (m=16, x^2 mod 16), "
-                    "or 'mux' / 'mux_naive'")
+                    "or 'mux' / 'mux_naive', or 'mixed' = half hom_mux + half hom_xor (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU sample")
     return ap.parse_args()
@@ -89,7 +89,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     P = R.params.PARAM_SETS[args.params]
-    special = args.gate in ("pbs", "mux", "mux_naive")
+    special = args.gate in ("pbs", "mux", "mux_naive", "mixed")
     gate = None if special else R.engine.GATE_IDS[args.gate]
     B = args.batch
 
@@ -111,7 +111,7 @@ def main():
     else:
         ca = sk.encrypt_bool(bits_a, seed=11 + 3 * rank)
         cb = sk.encrypt_bool(bits_b, seed=12 + 3 * rank)
-    cc = sk.encrypt_bool(bits_c, seed=13 + 3 * rank) if args.gate.startswith("mux") else None
+    cc = sk.encrypt_bool(bits_c, seed=13 + 3 * rank) if args.gate.startswith("mux") or args.gate == "mixed" else None
     lut = R.lut.Generator(16).generate_lookup_table(lambda x: (x * x) % 16) if args.gate == "pbs" else None
     setup_s = time.time() - t0
 
@@ -126,6 +126,10 @@ def main():
             eng.batch_bootstrap_dev(ta, to, testvec=tlut)
         elif args.gate.startswith("mux"):
             eng.batch_mux_dev(ta, tb, tc, to, naive=(args.gate == "mux_naive"))
+        elif args.gate == "mixed":  # BASELINE configs[4]: half hom_mux (reference formula), half hom_xor
+            h = B // 2
+            eng.batch_mux_dev(ta[:h], tb[:h], tc[:h], to[:h], naive=False)
+            eng.batch_gate_dev(R.engine.XOR, ta[h:], tb[h:], to[h:])
         else:
             eng.batch_gate_dev(gate, ta, tb, to)
 
@@ -159,6 +163,9 @@ def main():
         decrypt_ok = bool(np.array_equal(sk.decrypt_lwe_message(out, 16), (msgs ** 2) % 16))
     elif args.gate == "mux":
         decrypt_ok = None  # Gates::mux is the reference formula: no decrypt claim
+    elif args.gate == "mixed":  # claim only the xor half (the mux half is the Q5 formula)
+        h = B // 2
+        decrypt_ok = bool(np.array_equal(sk.decrypt_bool(out[h:]), bits_a[h:] ^ bits_b[h:]))
     elif args.gate == "mux_naive":
         decrypt_ok = bool(np.array_equal(sk.decrypt_bool(out), np.where(bits_a, bits_b, bits_c)))
     else:
@@ -169,7 +176,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    boots_per_item = 3 if args.gate.startswith("mux") else 1  # mux and mux_naive count 3
+    # mux and mux_naive count 3 bootstraps, a plain gate 1; "mixed" is half and half
+    boots_per_item = 3 if args.gate.startswith("mux") else (2 if args.gate == "mixed" else 1)
     value = world * B * boots_per_item * args.steps / elapsed
     bytes_per_bootstrap = P.algorithmic_bytes_per_bootstrap(1 if args.gate == "pbs" else 2)
     # dominant kernel: k_blind_rotate.  Algorithmic bytes per launch = B * (BSK once +
