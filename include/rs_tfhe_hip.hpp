@@ -76,6 +76,20 @@ struct Ciphertext {
   Torus &b_mut() { return p.back(); }
 };
 
+// src/tlwe.rs:129-214: Add, Sub, Neg, AddMul, SubMul on all n+1 words, wrapping (host side, as in the
+// reference; tfhe_hip_batch_tlwe_lincomb[_dev] is the batched device form)
+inline Ciphertext lincomb(Torus ca, const Ciphertext &a, Torus cb, const Ciphertext &b) {
+  if (a.p.size() != b.p.size()) throw std::runtime_error("TLWE operands differ in dimension");
+  Ciphertext r(a.n());
+  for (size_t i = 0; i < a.p.size(); ++i) r.p[i] = ca * a.p[i] + cb * b.p[i];
+  return r;
+}
+inline Ciphertext operator+(const Ciphertext &a, const Ciphertext &b) { return lincomb(1u, a, 1u, b); }
+inline Ciphertext operator-(const Ciphertext &a, const Ciphertext &b) { return lincomb(1u, a, ~0u, b); }
+inline Ciphertext operator-(const Ciphertext &a) { return lincomb(~0u, a, 0u, a); }
+inline Ciphertext add_mul(const Ciphertext &a, const Ciphertext &b, Torus k) { return lincomb(1u, a, k, b); }
+inline Ciphertext sub_mul(const Ciphertext &a, const Ciphertext &b, Torus k) { return lincomb(1u, a, 0u - k, b); }
+
 // ---- src/trlwe.rs:11-14 --------------------------------------------------------------
 struct TRLWELv1 {
   std::array<Torus, N> a{};

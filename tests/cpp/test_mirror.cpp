@@ -184,6 +184,20 @@ int main() {
       CHECK(tlwe::decrypt_lwe_message(c, 4, sk.key_lv0) == m, "message round trip %zu", m);
       CHECK((int)tlwe::decrypt_lwe_message(c, 4, sk.key_lv0) == orc_tlwe_decrypt_lwe_message(c.p.data(), 4, sk.key_lv0.data(), P.n), "message decoders agree");
     }
+    // TLWE arithmetic (tlwe.rs:129-214) and the first step of examples/lut_add_two_numbers.rs:
+    // bootstrap_lut(&(&x + &y), &lut): 1 + 2 = 3 under modulus 4
+    {
+      Ciphertext x = tlwe::encrypt_lwe_message(1, 4, P.alpha_lv0, sk.key_lv0, rng), y = tlwe::encrypt_lwe_message(2, 4, P.alpha_lv0, sk.key_lv0, rng);
+      CHECK(tlwe::decrypt_lwe_message(x + y, 4, sk.key_lv0) == 3, "x + y");
+      CHECK(tlwe::decrypt_lwe_message((x + y) - y, 4, sk.key_lv0) == 1, "(x + y) - y");
+      CHECK(tlwe::decrypt_lwe_message(add_mul(x, x, 2), 4, sk.key_lv0) == 3, "add_mul");
+      Ciphertext z = -x;
+      CHECK(z.p[0] == 0u - x.p[0] && z.b() == 0u - x.b(), "neg");
+      lut::Generator gen(4);
+      LutBootstrap lb;
+      Ciphertext r = lb.bootstrap_lut(x + y, gen.generate_lookup_table([](size_t v) { return (v + 1) % 4; }), gk);
+      CHECK(tlwe::decrypt_lwe_message(r, 4, sk.key_lv0) == 0, "bootstrap_lut(x + y)");
+    }
     // a different key object at the same address must not be mistaken for the loaded one
     CloudKey *slot = new CloudKey(gk);
     CHECK(tlwe::decrypt_bool(g.nand(tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, rng), tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, rng), *slot), sk.key_lv0) == false, "copy of the key");
