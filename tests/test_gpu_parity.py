@@ -947,3 +947,38 @@ def test_lut_nibble_adder_circuit(O, eng128, keys128, keys_uint4):
     # n = 820 mask words rounded to 2N positions leave ~2.7 sigma per bootstrap at modulus 32
     assert (res == want).mean() >= 0.9
     assert np.array_equal(sk4.decrypt_lwe_message(cr, 32)[res == want], ((a & 15) + (b & 15) >= 16)[res == want])
+
+
+def test_one_context_from_several_threads(O, eng128, keys128):
+    """`Bootstrap: Send + Sync` (src/bootstrap/mod.rs:23): one context called concurrently from several
+    host threads (ctypes releases the GIL for the duration of a call) must serialise internally and
+    give every caller its own, correct result."""
+    import threading
+
+    sk, ck = keys128
+    rng = np.random.default_rng(61)
+    jobs = []
+    for t in range(6):
+        n = int(rng.integers(1, 40))
+        A = rng.integers(0, 2, n).astype(bool)
+        B = rng.integers(0, 2, n).astype(bool)
+        jobs.append((t % 10, A, B, sk.encrypt_bool(A, 6100 + 2 * t), sk.encrypt_bool(B, 6101 + 2 * t)))
+    results = [None] * len(jobs)
+    errors = []
+
+    def work(i):
+        try:
+            gate, _, _, ca, cb = jobs[i]
+            for _ in range(3):  # repeated, interleaved with the other threads
+                results[i] = eng128.batch_gate(gate, ca, cb)
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors
+    for (gate, A, B, ca, cb), got in zip(jobs, results):
+        assert np.array_equal(got, O.batch_gate(ck, gate, ca, cb))
