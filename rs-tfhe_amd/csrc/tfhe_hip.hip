@@ -7,7 +7,6 @@
 // (src/gates.rs:357-383: prepare, batch_blind_rotate, extract + key switch).
 #include <hip/hip_runtime.h>
 
-#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,9 +60,6 @@ struct tfhe_hip_ctx {
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
-  hipStream_t copy_stream = nullptr;    // host-pointer entry points: transfers of one chunk beside compute of another
-  std::vector<hipEvent_t> ev_copy;      // [2 * chunk]: inputs landed / outputs ready
-  size_t host_chunk = 32768;            // ciphertexts per chunk of the pipelined host path (0 = off)
   hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
   bool scratch_owned = false;
 };
@@ -396,49 +392,6 @@ int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
   return TFHE_HIP_OK;
 }
 
-// Host-pointer batches of several chunks: the transfers of one chunk run on a second stream beside the
-// compute of another (inputs of chunk c+1 while chunk c computes, outputs of chunk c-1 likewise), so only
-// the first upload and the last download stay exposed.  Chunks are large (>= 32 k ciphertexts) because
-// the group key-switch kernels lose efficiency on small launches.
-int host_gate_pipelined(tfhe_hip_ctx *ctx, int gate, bool has_b, const uint32_t *a, const uint32_t *b, uint32_t *out,
-                        size_t count) {
-  const size_t w = (size_t)ctx->P.n + 1;
-  const size_t per = ctx->host_chunk, chunks = (count + per - 1) / per;
-  if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-  while (ctx->ev_copy.size() < 2 * chunks) {
-    hipEvent_t e;
-    HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    ctx->ev_copy.push_back(e);
-  }
-  CHK(ensure(ctx, ctx->h_a, count * w * 4));
-  if (has_b) CHK(ensure(ctx, ctx->h_b, count * w * 4));
-  CHK(ensure(ctx, ctx->h_out, count * w * 4));
-  CHK(ensure(ctx, ctx->lv1, std::min(per, count) * (size_t)(kN + 1) * 4));  // no reallocation mid-pipeline
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // earlier work on the staging buffers is done
-  uint32_t *da = (uint32_t *)ctx->h_a.p, *db = (uint32_t *)ctx->h_b.p, *dout = (uint32_t *)ctx->h_out.p;
-  hipStream_t cs = ctx->copy_stream;
-  auto download = [&](size_t c) -> int {
-    const size_t lo = c * per, m = std::min(per, count - lo);
-    HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->ev_copy[2 * c + 1], 0));
-    HIPCHK(ctx, hipMemcpyAsync(out + lo * w, dout + lo * w, m * w * 4, hipMemcpyDeviceToHost, cs));
-    return TFHE_HIP_OK;
-  };
-  for (size_t c = 0; c < chunks; ++c) {
-    const size_t lo = c * per, m = std::min(per, count - lo);
-    HIPCHK(ctx, hipMemcpyAsync(da + lo * w, a + lo * w, m * w * 4, hipMemcpyHostToDevice, cs));
-    if (has_b) HIPCHK(ctx, hipMemcpyAsync(db + lo * w, b + lo * w, m * w * 4, hipMemcpyHostToDevice, cs));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_copy[2 * c], cs));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_copy[2 * c], 0));
-    CHK(gate_dev(ctx, gate, da + lo * w, has_b ? db + lo * w : nullptr, dout + lo * w, m, ctx->stream));
-    HIPCHK(ctx, hipEventRecord(ctx->ev_copy[2 * c + 1], ctx->stream));
-    if (c > 0) CHK(download(c - 1));
-  }
-  CHK(download(chunks - 1));
-  HIPCHK(ctx, hipStreamSynchronize(cs));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return TFHE_HIP_OK;
-}
-
 void make_twiddles(std::vector<double2> &tw) {
   tw.resize(576);
   const long double pi = 3.14159265358979323846264338327950288L;
@@ -520,7 +473,6 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
-  if (const char *env = getenv("TFHE_HIP_HOST_CHUNK")) ctx->host_chunk = (size_t)atol(env);
   std::vector<double2> tw;
   make_twiddles(tw);
   if ((e = hipMalloc((void **)&ctx->d_tw, tw.size() * sizeof(double2))) != hipSuccess)
@@ -545,8 +497,6 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
   }
-  for (hipEvent_t e : ctx->ev_copy) (void)hipEventDestroy(e);
-  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
@@ -773,7 +723,6 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
   if (!a || !out || (gp.cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
-  if (ctx->host_chunk && count >= 2 * ctx->host_chunk) return host_gate_pipelined(ctx, gate, gp.cb != 0, a, b, out, count);
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   if (gp.cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
   CHK(ensure(ctx, ctx->h_out, bytes));
