@@ -214,9 +214,10 @@ int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, cons
 int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
                                     const int32_t *bsk_index, uint32_t *trlwe_out, size_t count);
 
-/* Replaces: trlwe::sample_extract_index(.,0) (src/trlwe.rs:106-120).
+/* Replaces: trlwe::sample_extract_index(., k) (src/trlwe.rs:106-120), 0 <= k < N (the bootstrap uses
+ * k = 0): out[i] = a[k-i] for i <= k, MAX - a[N+k-i] for i > k, out[N] = b[k].
  * trlwe [count][2][N] -> out [count][N+1]. */
-int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, uint32_t *out,
+int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, int k, uint32_t *out,
                                   size_t count);
 
 /* Replaces: trgsw::identity_key_switching (src/trgsw.rs:332-360).

@@ -68,7 +68,7 @@ SIGNATURES = {
     "tfhe_hip_batch_mux": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_mux_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_external_product": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
-    "tfhe_hip_batch_sample_extract": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_sample_extract": (C.c_int, [_CTX, _P, C.c_int, _P, _SZ]),
     "tfhe_hip_batch_identity_key_switch": (C.c_int, [_CTX, _P, _P, _SZ]),
     "tfhe_hip_batch_ifft": (C.c_int, [_CTX, _P, _P, _SZ]),
     "tfhe_hip_batch_fft": (C.c_int, [_CTX, _P, _P, _SZ]),

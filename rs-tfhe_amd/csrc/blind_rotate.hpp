@@ -585,18 +585,18 @@ __global__ __launch_bounds__(64) void k_poly_mul(const uint32_t *a, const uint32
   }
 }
 
-// sample_extract_index(.,0)  (trlwe.rs:106-120): [count][2][N] -> [count][N+1]
-__global__ void k_sample_extract(const uint32_t *trlwe, uint32_t *out, size_t count) {
+// sample_extract_index(., k)  (trlwe.rs:106-120): [count][2][N] -> [count][N+1]
+__global__ void k_sample_extract(const uint32_t *trlwe, int k, uint32_t *out, size_t count) {
   size_t ct = blockIdx.x;
   const uint32_t *a = trlwe + ct * (size_t)(2 * kN);
   uint32_t *o = out + ct * (size_t)(kN + 1);
   for (int i = threadIdx.x; i <= kN; i += blockDim.x) {
-    if (i == 0)
-      o[0] = a[0];
-    else if (i < kN)
-      o[i] = ~a[kN - i];
+    if (i == kN)
+      o[kN] = a[kN + k];  // b[k]
+    else if (i <= k)
+      o[i] = a[k - i];
     else
-      o[kN] = a[kN];  // b[0]
+      o[i] = ~a[kN + k - i];  // Torus::MAX - a[N + k - i]
   }
 }
 

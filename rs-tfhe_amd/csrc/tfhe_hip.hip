@@ -878,9 +878,10 @@ int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
   return to_host(ctx, trlwe_out, ctx->h_out, bytes);
 }
 
-int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, uint32_t *out, size_t count) {
+int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, int k, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (k < 0 || k >= kN) return fail(ctx, TFHE_HIP_EINVAL, "extraction index out of range");
   if (count == 0) return TFHE_HIP_OK;
   if (!trlwe || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -888,7 +889,7 @@ int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, uint
   const size_t obytes = count * (size_t)(kN + 1) * 4;
   CHK(ensure(ctx, ctx->h_out, obytes));
   hipLaunchKernelGGL(k_sample_extract, dim3((unsigned)count), dim3(256), 0, ctx->stream,
-                     (const uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_out.p, count);
+                     (const uint32_t *)ctx->h_a.p, k, (uint32_t *)ctx->h_out.p, count);
   HIPCHK(ctx, hipGetLastError());
   return to_host(ctx, out, ctx->h_out, obytes);
 }

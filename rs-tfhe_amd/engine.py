@@ -226,10 +226,10 @@ class Engine:
         self._chk(self._lib.tfhe_hip_batch_external_product(self._ctx, _ptr(trlwe), _ptr(idx), _ptr(out), len(trlwe)))
         return out
 
-    def batch_sample_extract(self, trlwe) -> np.ndarray:
+    def batch_sample_extract(self, trlwe, k: int = 0) -> np.ndarray:
         trlwe = _u32(trlwe).reshape(-1, 2, N)
         out = np.empty((len(trlwe), N + 1), np.uint32)
-        self._chk(self._lib.tfhe_hip_batch_sample_extract(self._ctx, _ptr(trlwe), _ptr(out), len(trlwe)))
+        self._chk(self._lib.tfhe_hip_batch_sample_extract(self._ctx, _ptr(trlwe), int(k), _ptr(out), len(trlwe)))
         return out
 
     def batch_identity_key_switch(self, lv1) -> np.ndarray:

@@ -115,6 +115,12 @@ def test_sample_extract_bit_exact(O, eng128):
     t = rng.integers(0, 2**32, (5, 2, N), dtype=np.uint64).astype(np.uint32)
     got = eng128.batch_sample_extract(t)
     assert np.array_equal(got, np.stack([O.sample_extract_index(x, 0) for x in t]))
+    for k in (1, 2, 511, 512, 1022, 1023):  # the reference tests every k (trlwe.rs:190-230)
+        assert np.array_equal(eng128.batch_sample_extract(t, k), np.stack([O.sample_extract_index(x, k) for x in t]))
+    from rs_tfhe_amd import _capi
+
+    with pytest.raises(_capi.TfheHipError):
+        eng128.batch_sample_extract(t, 1024)
 
 
 def test_key_switch_bit_exact(O, eng128, keys128):
