@@ -110,6 +110,33 @@ def test_external_product_exact_128(O, eng128, keys128):
         assert np.array_equal(gg, O.external_product_fft(ck.bootstrapping_key[i], x, P.l, P.bgbit, ck.decomposition_offset))
 
 
+def test_cmux_selects_and_matches(O, eng128, keys128):
+    """trgsw::cmux (trgsw.rs:174-196) = in1 + ExtProd(cond, in2 - in1), composed from the external
+    product stage: word-for-word against the CPU path, and it selects by the key bit (the reference's
+    own cmux test, trgsw.rs:469-505: BSK[i] encrypts key_lv0[i])."""
+    sk, ck = keys128
+    P = ck.params
+    rng = np.random.default_rng(125)
+    idx = np.array([0, 7, 123, 350, 699], np.int32)
+    # in1 / in2: trivial TRLWE samples (a = 0) carrying +1/8 and -1/8 in every coefficient
+    in1 = np.zeros((len(idx), 2, N), np.uint32)
+    in2 = np.zeros((len(idx), 2, N), np.uint32)
+    in1[:, 1, :] = 0x20000000
+    in2[:, 1, :] = 0xE0000000
+    got = in1 + eng128.batch_external_product(in2 - in1, idx)
+    for i, x1, x2, g in zip(idx, in1, in2, got):
+        assert np.array_equal(g, O.cmux(x1, x2, ck.bootstrapping_key[i], P.l, P.bgbit, ck.decomposition_offset))
+        picked_second = bool(sk.key_lv0[i])  # cond = 1 selects in2
+        phase = sk.trlwe_phase(g).view(np.int32)
+        assert ((phase < 0) == picked_second).all()
+    # random (non-trivial) operands: still word for word
+    r1 = rng.integers(0, 2**32, (len(idx), 2, N), dtype=np.uint64).astype(np.uint32)
+    r2 = rng.integers(0, 2**32, (len(idx), 2, N), dtype=np.uint64).astype(np.uint32)
+    got = r1 + eng128.batch_external_product(r2 - r1, idx)
+    for i, x1, x2, g in zip(idx, r1, r2, got):
+        assert np.array_equal(g, O.cmux(x1, x2, ck.bootstrapping_key[i], P.l, P.bgbit, ck.decomposition_offset))
+
+
 def test_sample_extract_bit_exact(O, eng128):
     rng = np.random.default_rng(25)
     t = rng.integers(0, 2**32, (5, 2, N), dtype=np.uint64).astype(np.uint32)
