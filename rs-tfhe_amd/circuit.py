@@ -30,6 +30,7 @@ class Circuit:
     gates: list = field(default_factory=list)
     _level: dict = field(default_factory=dict)
     _n_wires: int = 0
+    _plans: dict = field(default_factory=dict)  # (device, n_gates) -> per-level index / gate-code tensors
 
     def __post_init__(self):
         self._n_wires = self.n_inputs
@@ -102,18 +103,31 @@ class Circuit:
         assert n_in == self.n_inputs
         wires = torch.empty((self.n_wires, B, w), dtype=torch.int32, device=inputs.device)
         wires[:n_in] = inputs
-        for lvl in self.levels():
-            ia = torch.tensor([g.a for g in lvl], device=inputs.device)
-            ib = torch.tensor([g.b for g in lvl], device=inputs.device)
-            io = torch.tensor([g.out for g in lvl], device=inputs.device)
-            codes = torch.tensor([g.op for g in lvl], dtype=torch.uint8, device=inputs.device)
+        for ia, ib, io, codes in self._plan(inputs.device):
             a = wires.index_select(0, ia).reshape(-1, w)
             b = wires.index_select(0, ib).reshape(-1, w)
             gc = codes.repeat_interleave(B).contiguous()
             out = torch.empty_like(a)
             eng.batch_gates_mixed_dev(gc, a, b, out, stream)
-            wires.index_copy_(0, io, out.reshape(len(lvl), B, w))
+            wires.index_copy_(0, io, out.reshape(len(io), B, w))
         return wires
+
+    def _plan(self, device):
+        """Per-level operand / result wire indices and gate codes as device tensors, built once per
+        (device, circuit size): repeated runs of the same circuit upload nothing but their inputs."""
+        import torch
+
+        key = (str(device), len(self.gates))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = []
+            for lvl in self.levels():
+                plan.append((torch.tensor([g.a for g in lvl], device=device),
+                             torch.tensor([g.b for g in lvl], device=device),
+                             torch.tensor([g.out for g in lvl], device=device),
+                             torch.tensor([g.op for g in lvl], dtype=torch.uint8, device=device)))
+            self._plans[key] = plan
+        return plan
 
     def run(self, eng: E.Engine, inputs) -> np.ndarray:
         """Host convenience: inputs uint32 [n_inputs][B][n+1] -> all wires uint32 [n_wires][B][n+1]."""
