@@ -117,3 +117,33 @@ def test_gates_api_surface():
     a = np.arange(5, dtype=np.uint32)
     assert np.array_equal(g.not_(a), (0 - a.astype(np.int64)).astype(np.uint32))
     assert g.constant(True, 4)[4] == 0x20000000 and g.constant(False, 4)[4] == 0xE0000001  # quirk Q6
+
+
+def test_kernels_compile_without_scratch_and_keep_their_occupancy():
+    """Register-allocation guard: every gfx950 kernel of the library must compile with zero scratch
+    (a 12-register spill in the l = 1 blind rotation cost 9 % before it was noticed), the batch blind
+    rotation must keep two waves per SIMD and the LDS-ring key switch three."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "rs-tfhe_amd", "csrc", "tfhe_hip.hip")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", "--cuda-device-only",
+                        "-c", "-o", os.devnull, "-Rpass-analysis=kernel-resource-usage", src],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", r.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", r.stderr)]
+    occ = [int(x) for x in re.findall(r"Occupancy \[waves/SIMD\]: (\d+)", r.stderr)]
+    assert len(names) == len(scratch) == len(occ) and len(names) > 20
+    spilled = {n: s for n, s in zip(names, scratch) if s}
+    assert not spilled, spilled
+    by_name = dict(zip(names, occ))
+    for n, o in by_name.items():
+        if "14k_blind_rotateI" in n:
+            assert o >= 2, (n, o)
+        if "k_key_switch_b4" in n:
+            assert o >= 3, (n, o)
