@@ -145,7 +145,8 @@ int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, cons
  * whatever its type.  Same semantics as count calls of the Gates method
  * (src/gates.rs:54-150); b is read for every gate but COPY.  The host entry rejects codes
  * above TFHE_HIP_COPY with TFHE_HIP_EINVAL; the _dev entry cannot read device memory on the
- * host and treats them as COPY. */
+ * host: the kernel treats such a ciphertext as COPY and raises a device-side flag that the next
+ * tfhe_hip_synchronize() reports as TFHE_HIP_EINVAL. */
 int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
                                const uint32_t *b, uint32_t *out, size_t count);
 int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
@@ -255,7 +256,22 @@ typedef struct tfhe_hip_kernel_times {
  * resets them. */
 int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out);
 
-/* Block until everything enqueued on the context's own stream has finished. */
+/* Shader clock actually sustained by the blind-rotation kernel: while profiling is enabled every
+ * workgroup adds its s_memtime (shader cycles) and s_memrealtime (constant-rate counter) deltas to a
+ * device counter; shader_mhz = cycles / ticks * rtc_mhz over all workgroups since the last call.
+ * Synchronises, returns the sample and resets it.  (Needed to price the kernel against the FP64
+ * issue roofline at the clock the chip really ran, not at the 2.4 GHz datasheet maximum.) */
+typedef struct tfhe_hip_clock_sample {
+  double shader_mhz;       /* 0 when nothing was sampled */
+  double rtc_mhz;          /* rate of the constant counter (hipDeviceAttributeWallClockRate) */
+  uint64_t shader_cycles;  /* summed over workgroups */
+  uint64_t rtc_ticks;
+} tfhe_hip_clock_sample;
+int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
+
+/* Block until everything this context enqueued -- on its own stream and on the caller's stream of the
+ * last *_dev call -- has finished.  Returns TFHE_HIP_EINVAL (and clears the condition) if a
+ * tfhe_hip_batch_gates_mixed_dev launch since the last call met a gate code outside tfhe_hip_gate. */
 int tfhe_hip_synchronize(tfhe_hip_ctx *ctx);
 
 #ifdef __cplusplus

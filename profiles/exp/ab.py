@@ -1,0 +1,110 @@
+#!/usr/bin/env python3
+"""A/B harness for kernel variants: every variant is a build of libtfhe_hip.so (same C ABI, different -D
+knobs, see profiles/exp/build_variants.sh).  Each runs in its own process (TFHE_HIP_LIB) on the same seeded
+key and ciphertexts; rounds are interleaved (cdna_hip_programming.md rule 24).  Prints, per variant, the
+blind-rotate / key-switch launch times (HIP events), the sampled shader clock, and a digest of the output
+ciphertexts -- every correct variant must print the same digest as the checked baseline.
+
+    python3 profiles/exp/ab.py [--rounds 2] [--batch 65536] [--params SECURITY_128_BIT] libA.so libB.so ...
+"""
+import argparse
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def child(args):
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch
+
+    import rs_tfhe_amd as R
+
+    P = R.params.PARAM_SETS[args.params]
+    dev = torch.device("cuda", 0)
+    sk = R.SecretKey.new(P, seed=2024)
+    eng = R.Engine(P, 0)
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+    rng = np.random.default_rng(1000)
+    B = args.batch
+    ba, bb = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    if args.gate == "pbs":
+        msgs = rng.integers(0, 16, B)
+        ca = sk.encrypt_lwe_message(msgs, 16, seed=11)
+        cb = ca
+        lut = R.lut.Generator(16).generate_lookup_table(lambda x: (x * x) % 16)
+        tlut = torch.from_numpy(lut.poly.view(np.int32)).to(dev)
+    else:
+        ca, cb = sk.encrypt_bool(ba, seed=11), sk.encrypt_bool(bb, seed=12)
+    ta = torch.from_numpy(ca.view(np.int32)).to(dev)
+    tb = torch.from_numpy(cb.view(np.int32)).to(dev)
+    to = torch.empty_like(ta)
+
+    def step():
+        if args.gate == "pbs":
+            eng.batch_bootstrap_dev(ta, to, testvec=tlut)
+        else:
+            eng.batch_gate_dev(R.engine.GATE_IDS[args.gate], ta, tb, to)
+
+    step()
+    torch.cuda.synchronize()
+    eng.kernel_times()
+    eng.set_profiling(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    clk = eng.clock_sample() if hasattr(eng, "clock_sample") and hasattr(eng._lib, "tfhe_hip_get_clock_sample") else {}
+    out = to.cpu().numpy().view(np.uint32)
+    if args.gate == "pbs":
+        ok = bool(np.array_equal(sk.decrypt_lwe_message(out, 16), (msgs ** 2) % 16))
+        digest = hashlib.sha256(sk.decrypt_lwe_message(out, 16).tobytes()).hexdigest()[:16]  # f64 tolerance set: messages
+    else:
+        ok = bool(np.array_equal(sk.decrypt_bool(out), ~(ba & bb))) if args.gate == "nand" else None
+        digest = hashlib.sha256(out.tobytes()).hexdigest()[:16]
+    print(json.dumps({"br_ms": kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"]),
+                      "ks_ms": kt["key_switch_ms"] / max(1, kt["key_switch_launches"]),
+                      "mhz": round(clk.get("shader_mhz", 0.0), 1), "digest": digest, "decrypt_ok": ok}))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("libs", nargs="*")
+    ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--params", default="SECURITY_128_BIT")
+    ap.add_argument("--gate", default="nand")
+    ap.add_argument("--child", action="store_true")
+    args = ap.parse_args()
+    if args.child:
+        return child(args)
+    res = {}
+    for r in range(args.rounds):
+        for lib in args.libs:
+            env = dict(os.environ, TFHE_HIP_LIB=os.path.abspath(lib))
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--steps", str(args.steps),
+                                "--batch", str(args.batch), "--params", args.params, "--gate", args.gate],
+                               env=env, capture_output=True, text=True, timeout=900)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not line:
+                print(f"{lib}: FAILED rc={p.returncode}\n{p.stdout[-800:]}\n{p.stderr[-1500:]}", flush=True)
+                continue
+            d = json.loads(line[-1])
+            res.setdefault(lib, []).append(d)
+            print(f"round {r} {os.path.basename(lib):28s} br {d['br_ms']:8.2f} ms  ks {d['ks_ms']:6.2f} ms  "
+                  f"{d['mhz']:7.1f} MHz  digest {d['digest']}  decrypt_ok {d['decrypt_ok']}", flush=True)
+    print("\nsummary (min / median blind-rotate ms over rounds)")
+    for lib, ds in res.items():
+        v = sorted(d["br_ms"] for d in ds)
+        print(f"  {os.path.basename(lib):28s} min {v[0]:8.2f}  med {v[len(v) // 2]:8.2f}  "
+              f"ks {min(d['ks_ms'] for d in ds):6.2f}  mhz {ds[-1]['mhz']}  digest {ds[-1]['digest']}")
+
+
+if __name__ == "__main__":
+    main()

@@ -38,6 +38,13 @@ class KernelTimes(C.Structure):
     ]
 
 
+class ClockSample(C.Structure):
+    """struct tfhe_hip_clock_sample"""
+
+    _fields_ = [("shader_mhz", C.c_double), ("rtc_mhz", C.c_double), ("shader_cycles", C.c_uint64),
+                ("rtc_ticks", C.c_uint64)]
+
+
 _P = C.c_void_p
 _SZ = C.c_size_t
 _CTX = C.c_void_p
@@ -75,6 +82,7 @@ SIGNATURES = {
     "tfhe_hip_batch_poly_mul": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
     "tfhe_hip_set_profiling": (C.c_int, [_CTX, C.c_int]),
     "tfhe_hip_get_kernel_times": (C.c_int, [_CTX, C.POINTER(KernelTimes)]),
+    "tfhe_hip_get_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
 }
 

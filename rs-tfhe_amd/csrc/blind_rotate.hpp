@@ -38,7 +38,16 @@ __device__ __forceinline__ uint32_t rot_read(const P *p, int j, int k) {
 using f64x2 = __attribute__((ext_vector_type(2))) double;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
+#ifndef TFHE_ABL_NOKEY  // timing-only ablation (results wrong by construction): no key loads
+#define TFHE_ABL_NOKEY 0
+#endif
 __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, uint32_t soff) {
+  if (TFHE_ABL_NOKEY) {
+    f64x2 r;
+    r.x = (double)(lane_off + soff);
+    r.y = (double)(lane_off ^ soff);
+    return r;
+  }
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off, (int)soff, 0);
   return __builtin_bit_cast(f64x2, v);
 }
@@ -50,18 +59,24 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 // In:  t_lo/hi[m] = (coefficient + decomposition offset), folded-FFT distribution
 //      (lane l: coefficients l+64m and l+64m+512).
 // Acc: fa / fb = the two accumulated spectra (un-normalised; the key carries 2^-10)
-//      in the forward-FFT bin order, ready for fft_inverse.
+//      in the forward-FFT bin order, ready for fft_inverse.  INIT0: the first row
+//      WRITES the accumulators (no zero fill, no add).
 //      (decomposition trgsw.rs:144-171, batch_ifft + fma_in_fd_1024 trgsw.rs:99-106)
-// How many of the 8 b-half key loads of a row are issued before the forward FFT (the 8
-// a-half loads always are).  8 = whole row in flight across the FFT (64 VGPRs).
+// TFHE_ROW_UNROLL: 0 = the digit-row loop stays a loop (smallest code), 1 = unrolled.
+#ifndef TFHE_ROW_UNROLL
+#define TFHE_ROW_UNROLL 0
+#endif
+// How many of the 8 a-half / b-half key loads of a row are issued before the forward FFT.
 #ifndef TFHE_PREFETCH_A
 #define TFHE_PREFETCH_A 8
 #endif
 #ifndef TFHE_PREFETCH_B
-#define TFHE_PREFETCH_B 0
+#define TFHE_PREFETCH_B 8
 #endif
-constexpr int kPrefetchA = TFHE_PREFETCH_A;
-constexpr int kPrefetchB = TFHE_PREFETCH_B;
+// 1 = the two inverse transforms of a CMUX step are interleaved through the one tile (fft_inverse2)
+#ifndef TFHE_INV_PAIR
+#define TFHE_INV_PAIR 1
+#endif
 
 // Signed bit-field extract (v_bfe_i32).  Written as inline asm on purpose: with
 // __builtin_amdgcn_sbfe and a run-time width, hipcc (ROCm 7.2 / clang 22) turns the following
@@ -73,7 +88,61 @@ __device__ __forceinline__ int32_t sbfe(uint32_t src, int shift, int width) {
   return d;
 }
 
-template <int L>
+// f (+)= x * v, complex, as four fused multiply-adds (fma_in_fd_1024, trgsw.rs:118-142; the 0.5 of the
+// reference is in the key's 2^-10).  Written with explicit fma(): from `f += xr*v.x - xi*v.y` the
+// compiler makes mul + fma + add.
+template <bool INIT>
+__device__ __forceinline__ void cmac(double &fr, double &fi, double xr, double xi, f64x2 v) {
+  if (INIT) {
+    fr = xr * v.x;
+    fi = xr * v.y;
+  } else {
+    fr = fma(xr, v.x, fr);
+    fi = fma(xr, v.y, fi);
+  }
+  fr = fma(-xi, v.y, fr);
+  fi = fma(xi, v.x, fi);
+}
+
+// One decomposition row: digit extraction, forward transform, multiply-accumulate against key row r.
+template <int L, bool INIT>
+__device__ __forceinline__ void external_product_row(int r, int shift, const uint32_t (&w_lo)[8],
+                                                     const uint32_t (&w_hi)[8], __amdgpu_buffer_rsrc_t bsk_rsrc,
+                                                     uint32_t bsk_i_off, const Twiddles &tw, double2 *tile,
+                                                     int lane, int bgbit, double (&fa_re)[8], double (&fa_im)[8],
+                                                     double (&fb_re)[8], double (&fb_im)[8]) {
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  // key row r: 2 x 8 coalesced 16-byte loads per lane off one buffer descriptor (lane
+  // offset in a VGPR, row offset in an SGPR: no per-lane address arithmetic), issued
+  // ahead of the FFT they are consumed after, so their latency hides under it.
+  const uint32_t row_off = bsk_i_off + (uint32_t)r * (2u * kN2 * 16u);
+  f64x2 va[8], vb[8];
+  // with a single digit row per half the schedule gets tighter: a whole a-half in flight spills there
+  constexpr int PA = (L == 1 && TFHE_PREFETCH_A > 6) ? 6 : TFHE_PREFETCH_A;
+  constexpr int PB = TFHE_PREFETCH_B;
+#pragma unroll
+  for (int s = 0; s < PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
+#pragma unroll
+  for (int s = 0; s < PB; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
+  double re[8], im[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    re[m] = (double)sbfe(w_lo[m], shift, bgbit);
+    im[m] = (double)sbfe(w_hi[m], shift, bgbit);
+  }
+  fft_forward(re, im, tw, tile, lane);
+  // the rest of the row is fetched behind the first MACs
+#pragma unroll
+  for (int s = PA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
+#pragma unroll
+  for (int s = PB; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<INIT>(fa_re[s], fa_im[s], re[s], im[s], va[s]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<INIT>(fb_re[s], fb_im[s], re[s], im[s], vb[s]);
+}
+
+template <int L, bool INIT0>
 __device__ __forceinline__ void external_product_half(int half_sel, const uint32_t (&t_lo)[8],
                                                       const uint32_t (&t_hi)[8],
                                                       __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
@@ -81,7 +150,6 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
                                                       uint32_t signmask, double (&fa_re)[8],
                                                       double (&fa_im)[8], double (&fb_re)[8],
                                                       double (&fb_im)[8]) {
-  const uint32_t lane_off = (uint32_t)lane * 16u;
   // digit_i = ((t >> shift_i) & (Bg-1)) - Bg/2  (trgsw.rs:162) = the sign-extended bgbit-wide
   // field of t ^ sum_i (Bg/2 << shift_i): flipping a field's top bit is subtracting Bg/2 mod Bg.
   // That sum is the decomposition offset itself (key.rs:78-89), so one XOR per coefficient
@@ -92,45 +160,88 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
     w_lo[m] = t_lo[m] ^ signmask;
     w_hi[m] = t_hi[m] ^ signmask;
   }
+  external_product_row<L, INIT0>(half_sel * L, 32 - bgbit, w_lo, w_hi, bsk_rsrc, bsk_i_off, tw, tile, lane, bgbit,
+                                 fa_re, fa_im, fb_re, fb_im);
+  // The remaining rows stay a LOOP: with the body duplicated (or, at L = 2, the one-trip loop flattened)
+  // the scheduler overlaps rows and spills; the trip count is hidden from it for that reason.
+  int rows = L;
+  if (L > 1 && !TFHE_ROW_UNROLL) asm volatile("" : "+s"(rows));
+#if TFHE_ROW_UNROLL
+#pragma unroll
+#else
 #pragma unroll 1
-  for (int i = 0; i < L; ++i) {
-    const int r = half_sel * L + i;
-    const int shift = 32 - (i + 1) * bgbit;
-    // key row r: 2 x 8 coalesced 16-byte loads per lane off one buffer descriptor (lane
-    // offset in a VGPR, row offset in an SGPR: no per-lane address arithmetic), issued
-    // ahead of the FFT they are consumed after, so their latency hides under it.
-    const uint32_t row_off = bsk_i_off + (uint32_t)r * (2u * kN2 * 16u);
-    f64x2 va[8], vb[8];
-    // with a single digit row per half the row loop disappears and the schedule gets tighter: a
-    // whole a-half in flight spills 12 registers there (measured: 236 ms vs 221 ms at SECURITY_UINT4)
-    constexpr int PA = (L == 1 && kPrefetchA > 6) ? 6 : kPrefetchA;
+#endif
+  for (int i = 1; i < rows; ++i)
+    external_product_row<L, false>(half_sel * L + i, 32 - (i + 1) * bgbit, w_lo, w_hi, bsk_rsrc, bsk_i_off, tw, tile,
+                                   lane, bgbit, fa_re, fa_im, fb_re, fb_im);
+}
+
+// ---- paired rows: two digit polynomials transformed together (fft_forward2), so that one's LDS
+// round trips are covered by the other's butterflies.  Rows r and r+1 may straddle the a / b halves
+// (L odd): each takes its digits from its own half's decomposition words.
+#ifndef TFHE_FWD_PAIR
+#define TFHE_FWD_PAIR 0
+#endif
+// 1 = the inverse-pass-3 twiddles (20 VGPRs) are re-read from the table before each inverse pair
+#ifndef TFHE_RELOAD_I3
+#define TFHE_RELOAD_I3 1
+#endif
+#ifndef TFHE_RELOAD_F3
+#define TFHE_RELOAD_F3 0
+#endif
+#ifndef TFHE_PAIR_SB
+#define TFHE_PAIR_SB 1
+#endif
+template <int L, bool INIT>
+__device__ __forceinline__ void external_product_row_pair(int rx, int shift_x, const uint32_t (&wx_lo)[8],
+                                                          const uint32_t (&wx_hi)[8], int shift_y,
+                                                          const uint32_t (&wy_lo)[8], const uint32_t (&wy_hi)[8],
+                                                          __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
+                                                          const Twiddles &tw, double2 *tile, int lane, int bgbit,
+                                                          double (&fa_re)[8], double (&fa_im)[8], double (&fb_re)[8],
+                                                          double (&fb_im)[8]) {
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  const uint32_t row_x = bsk_i_off + (uint32_t)rx * (2u * kN2 * 16u), row_y = row_x + 2u * kN2 * 16u;
+  f64x2 va[8], vb[8];
+#ifndef TFHE_PAIR_PA
+#define TFHE_PAIR_PA 8
+#endif
 #pragma unroll
-    for (int s = 0; s < PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
+  for (int s = 0; s < TFHE_PAIR_PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)s * 1024u);
+  double xr[8], xi[8], yr[8], yi[8];
 #pragma unroll
-    for (int s = 0; s < kPrefetchB; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
-    double re[8], im[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      re[m] = (double)sbfe(w_lo[m], shift, bgbit);
-      im[m] = (double)sbfe(w_hi[m], shift, bgbit);
-    }
-    fft_forward(re, im, tw, tile, lane);
-    // the rest of the row is fetched behind the first MACs
-#pragma unroll
-    for (int s = PA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
-#pragma unroll
-    for (int s = kPrefetchB; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)(kN2 * 16 + s * 1024));
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      fa_re[s] += re[s] * va[s].x - im[s] * va[s].y;
-      fa_im[s] += re[s] * va[s].y + im[s] * va[s].x;
-    }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      fb_re[s] += re[s] * vb[s].x - im[s] * vb[s].y;
-      fb_im[s] += re[s] * vb[s].y + im[s] * vb[s].x;
-    }
+  for (int m = 0; m < 8; ++m) {
+    xr[m] = (double)sbfe(wx_lo[m], shift_x, bgbit);
+    xi[m] = (double)sbfe(wx_hi[m], shift_x, bgbit);
+    yr[m] = (double)sbfe(wy_lo[m], shift_y, bgbit);
+    yi[m] = (double)sbfe(wy_hi[m], shift_y, bgbit);
   }
+  fft_forward2(xr, xi, yr, yi, tw, tile, lane);
+#if TFHE_PAIR_SB
+#define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PAIR_SB()
+#endif
+  PAIR_SB();  // keep the key loads below from being hoisted into the transforms (register pressure)
+#pragma unroll
+  for (int s = TFHE_PAIR_PA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)s * 1024u);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)(kN2 * 16 + s * 1024));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<INIT>(fa_re[s], fa_im[s], xr[s], xi[s], va[s]);
+  PAIR_SB();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_y + (uint32_t)s * 1024u);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<INIT>(fb_re[s], fb_im[s], xr[s], xi[s], vb[s]);
+  PAIR_SB();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_y + (uint32_t)(kN2 * 16 + s * 1024));
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<false>(fa_re[s], fa_im[s], yr[s], yi[s], va[s]);
+#pragma unroll
+  for (int s = 0; s < 8; ++s) cmac<false>(fb_re[s], fb_im[s], yr[s], yi[s], vb[s]);
+  PAIR_SB();
 }
 
 struct BlindRotateArgs {
@@ -149,6 +260,9 @@ struct BlindRotateArgs {
   uint32_t *out_trlwe;  // [count][2][N]
   uint32_t *out_lv1;    // [count][N+1]  sample_extract_index(.,0)
   uint32_t *out_ext2;   // [count][n+1]  sample_extract_index_2(.,0)
+  // diagnostics (may be null)
+  unsigned long long *clk;  // [2]: += shader cycles (s_memtime) and += constant-rate ticks (s_memrealtime) per workgroup
+  uint32_t *err_flag;       // |= 1 when a gate code outside tfhe_hip_gate is seen (the ciphertext is then treated as COPY)
 };
 
 // src/gates.rs:54-150 as (ca, cb, const): prepared = ca*a + cb*b, prepared.b += const.
@@ -179,6 +293,8 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
   const int lane = threadIdx.x;
   const size_t ct = blockIdx.x;
   const int n = A.n;
+  const unsigned long long clk0 = A.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rtc0 = A.clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   Twiddles tw;
   tw.load(A.tw, t2tab, lane);
@@ -186,7 +302,11 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
   // ---- gate linear prep + rotation amounts ---------------------------------
   uint32_t gca = A.ca, gcb = A.cb, gcc = A.cconst;
   if (A.gate_codes) {  // mixed batch: this ciphertext's own gate (same table as the host's gate_prep)
-    const uint32_t code = A.gate_codes[ct] < 11 ? A.gate_codes[ct] : 10u;
+    uint32_t code = A.gate_codes[ct];
+    if (code > 10u) {  // not a tfhe_hip_gate: flag it (the host reports it at the next synchronising call)
+      if (A.err_flag && lane == 0) atomicOr(A.err_flag, 1u);
+      code = 10u;
+    }
     gca = kGateCa[code];
     gcb = kGateCb[code];
     gcc = kGateCc[code];
@@ -226,14 +346,78 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int k = s_abar[i];
-    double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
+    double fa_re[8], fa_im[8], fb_re[8], fb_im[8];  // written by the first row of the a half
+#if TFHE_FWD_PAIR
+    {
+#if TFHE_RELOAD_F3
+      {
+        int z = 0;
+        asm volatile("" : "+v"(z));
+        tw.reload_f3(A.tw, lane, z);
+      }
+#endif
+      // decomposition words of both halves: w = (X^k*acc - acc + offset) ^ signmask  (trgsw.rs:183-186, 144-171)
+      uint32_t wa_lo[8], wa_hi[8], wb_lo[8], wb_hi[8];
+      const uint32_t *pb_ = acc + kN;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
+      for (int m = 0; m < 8; ++m) {
+        const int j = lane + 64 * m;
+        wa_lo[m] = (rot_read(acc, j, k) - acc[j] + offset) ^ signmask;
+        wa_hi[m] = (rot_read(acc, j + kN2, k) - acc[j + kN2] + offset) ^ signmask;
+      }
+      const uint32_t boff = (uint32_t)i * per_i_bytes;
+      const int bg = A.bgbit;
+      if (L == 1) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int j = lane + 64 * m;
+          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
+          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
+        }
+        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - bg, wb_lo, wb_hi, bsk_rsrc, boff, tw, tile,
+                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
+      } else if (L == 2) {
+        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - 2 * bg, wa_lo, wa_hi, bsk_rsrc, boff, tw, tile,
+                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int j = lane + 64 * m;
+          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
+          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
+        }
+        external_product_row_pair<L, false>(2, 32 - bg, wb_lo, wb_hi, 32 - 2 * bg, wb_lo, wb_hi, bsk_rsrc, boff, tw,
+                                            tile, lane, bg, fa_re, fa_im, fb_re, fb_im);
+      } else {
+        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - 2 * bg, wa_lo, wa_hi, bsk_rsrc, boff, tw, tile,
+                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const int j = lane + 64 * m;
+          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
+          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
+        }
+        external_product_row_pair<L, false>(2, 32 - 3 * bg, wa_lo, wa_hi, 32 - bg, wb_lo, wb_hi, bsk_rsrc, boff, tw, tile,
+                                            lane, bg, fa_re, fa_im, fb_re, fb_im);
+        external_product_row_pair<L, false>(4, 32 - 2 * bg, wb_lo, wb_hi, 32 - 3 * bg, wb_lo, wb_hi, bsk_rsrc, boff, tw,
+                                            tile, lane, bg, fa_re, fa_im, fb_re, fb_im);
+      }
+    }
+#else
     // cmux: tmp = in2 - in1 = X^k*acc - acc (trgsw.rs:183-186), + decomposition offset; the a
     // half is consumed before the b half is formed, so only 16 of these are ever live
+    {
+      uint32_t t_lo[8], t_hi[8];
 #pragma unroll
-    for (int half_sel = 0; half_sel < 2; ++half_sel) {
-      const uint32_t *p = acc + half_sel * kN;
+      for (int m = 0; m < 8; ++m) {
+        const int j = lane + 64 * m;
+        t_lo[m] = rot_read(acc, j, k) - acc[j] + offset;
+        t_hi[m] = rot_read(acc, j + kN2, k) - acc[j + kN2] + offset;
+      }
+      external_product_half<L, true>(0, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane, A.bgbit,
+                                     signmask, fa_re, fa_im, fb_re, fb_im);
+    }
+    {
+      const uint32_t *p = acc + kN;
       uint32_t t_lo[8], t_hi[8];
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
@@ -241,9 +425,28 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
         t_lo[m] = rot_read(p, j, k) - p[j] + offset;
         t_hi[m] = rot_read(p, j + kN2, k) - p[j + kN2] + offset;
       }
-      external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane,
-                               A.bgbit, signmask, fa_re, fa_im, fb_re, fb_im);
+      external_product_half<L, false>(1, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane, A.bgbit,
+                                      signmask, fa_re, fa_im, fb_re, fb_im);
     }
+#endif
+#if TFHE_RELOAD_I3
+    {
+      int z = 0;
+      asm volatile("" : "+v"(z));  // opaque 0: keeps the reload inside the loop (see Twiddles::reload_i3)
+      tw.reload_i3(A.tw, lane, z);
+    }
+#endif
+#if TFHE_INV_PAIR
+    fft_inverse2(fa_re, fa_im, fb_re, fb_im, tw, tile, lane);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
+      const int j = lane + 64 * m;
+      acc[j] += round_to_torus<FAST>(fa_re[m]);
+      acc[j + kN2] += round_to_torus<FAST>(fa_im[m]);
+      acc[kN + j] += round_to_torus<FAST>(fb_re[m]);
+      acc[kN + j + kN2] += round_to_torus<FAST>(fb_im[m]);
+    }
+#else
     fft_inverse(fa_re, fa_im, tw, tile, lane);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
@@ -258,6 +461,7 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
       acc[kN + j] += round_to_torus<FAST>(fb_re[m]);
       acc[kN + j + kN2] += round_to_torus<FAST>(fb_im[m]);
     }
+#endif
     wave_lds_sync();  // the next step re-reads acc at rotated (other lanes') positions
   }
 
@@ -282,6 +486,10 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
     uint32_t *o = A.out_ext2 + ct * (size_t)(n + 1);
     for (int i = lane; i < n; i += 64) o[i] = i == 0 ? acc[0] : ~acc[n - i];
     if (lane == 0) o[n] = acc[kN];
+  }
+  if (A.clk && lane == 0) {
+    atomicAdd(&A.clk[0], __builtin_amdgcn_s_memtime() - clk0);
+    atomicAdd(&A.clk[1], __builtin_amdgcn_s_memrealtime() - rtc0);
   }
 }
 
@@ -321,7 +529,11 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
 
   uint32_t gca = A.ca, gcb = A.cb, gcc = A.cconst;
   if (A.gate_codes) {
-    const uint32_t code = A.gate_codes[ct] < 11 ? A.gate_codes[ct] : 10u;
+    uint32_t code = A.gate_codes[ct];
+    if (code > 10u) {
+      if (A.err_flag && tid == 0) atomicOr(A.err_flag, 1u);
+      code = 10u;
+    }
     gca = kGateCa[code];
     gcb = kGateCb[code];
     gcc = kGateCc[code];
@@ -475,19 +687,27 @@ __global__ __launch_bounds__(64) void k_external_product(const uint32_t *in, con
 #pragma unroll
   for (int i = 0; i < L; ++i) signmask |= 1u << (32 - i * bgbit - 1);
   double fa_re[8], fa_im[8], fb_re[8], fb_im[8];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) fa_re[s] = fa_im[s] = fb_re[s] = fb_im[s] = 0.0;
-#pragma unroll
-  for (int half_sel = 0; half_sel < 2; ++half_sel) {
-    const uint32_t *p = in + ct * (size_t)(2 * kN) + half_sel * kN;
+  {
+    const uint32_t *p = in + ct * (size_t)(2 * kN);
     uint32_t t_lo[8], t_hi[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       t_lo[m] = p[lane + 64 * m] + offset;
       t_hi[m] = p[lane + 64 * m + kN2] + offset;
     }
-    external_product_half<L>(half_sel, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, signmask,
-                             fa_re, fa_im, fb_re, fb_im);
+    external_product_half<L, true>(0, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, signmask,
+                                   fa_re, fa_im, fb_re, fb_im);
+  }
+  {
+    const uint32_t *p = in + ct * (size_t)(2 * kN) + kN;
+    uint32_t t_lo[8], t_hi[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      t_lo[m] = p[lane + 64 * m] + offset;
+      t_hi[m] = p[lane + 64 * m + kN2] + offset;
+    }
+    external_product_half<L, false>(1, t_lo, t_hi, bsk_rsrc, idx * per_i_bytes, tw, tile, lane, bgbit, signmask,
+                                    fa_re, fa_im, fb_re, fb_im);
   }
   uint32_t *o = out + ct * (size_t)(2 * kN);
   fft_inverse(fa_re, fa_im, tw, tile, lane);
@@ -545,8 +765,8 @@ __global__ __launch_bounds__(64) void k_fft(const double *src, const double2 *tw
   fft_inverse(re, im, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    res[p * kN + lane + 64 * m] = round_to_torus(re[m]);
-    res[p * kN + lane + 64 * m + kN2] = round_to_torus(im[m]);
+    res[p * kN + lane + 64 * m] = round_half_away_to_torus(re[m]);  // f64::round, klemsa.rs:145-146
+    res[p * kN + lane + 64 * m + kN2] = round_half_away_to_torus(im[m]);
   }
 }
 
@@ -580,8 +800,8 @@ __global__ __launch_bounds__(64) void k_poly_mul(const uint32_t *a, const uint32
   fft_inverse(are, aim, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    res[p * kN + lane + 64 * m] = round_to_torus(are[m]);
-    res[p * kN + lane + 64 * m + kN2] = round_to_torus(aim[m]);
+    res[p * kN + lane + 64 * m] = round_half_away_to_torus(are[m]);
+    res[p * kN + lane + 64 * m + kN2] = round_half_away_to_torus(aim[m]);
   }
 }
 

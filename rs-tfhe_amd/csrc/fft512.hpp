@@ -4,28 +4,40 @@
 // folded to 512 complex points z[j] = x[j] + i*x[j+512] (the reference's
 // Klemsa fold, src/fft/klemsa.rs:88-101) and transformed with three radix-8
 // passes held in registers (8 complex points per lane), joined by two
-// transposes through a wave-private LDS tile.  The twist exp(i*pi*j/N) of the
-// reference (klemsa.rs:49-58,98-100) is split as
-//     exp(i*pi*(l+64m)/N) = exp(i*pi*l/N) * exp(i*pi*m/16)
-// -- the m part is a compile-time constant per register slot, the lane part is
-// merged into the first pass' twiddle, so the twist costs no extra pass.
+// transposes through a wave-private LDS tile.
 //
-// Forward (decimation in frequency), lane l, slot m holds z[l+64m]:
-//   pass 1: DFT-8 over m            -> k1, times T1[l][k1] = exp(i*pi*l*(1-4k1)/N)
-//   transpose A: (k1; l=l1+8*l2)    -> lane k1*8+l1, slot l2
-//   pass 2: DFT-8 over l2           -> k2, times T2[l1][k2] = exp(-2*pi*i*l1*k2/64)
-//   transpose B: (k1,l1; k2)        -> lane k1*8+k2, slot l1
-//   pass 3: DFT-8 over l1           -> k3
-//   result: lane mu, slot s holds bin k = (mu>>3) + 8*(mu&7) + 64*s
+// No twiddle is ever applied as a separate multiply.  With j = l1 + 8*l2 + 64*m
+// (lane l = l1 + 8*l2, slot m) and bin k = k1 + 8*k2 + 64*k3, the twist
+// exp(i*pi*j/N) of the reference (klemsa.rs:49-58,98-100) and every inter-pass
+// twiddle of the Cooley-Tukey split are GEOMETRIC in the slot index of the pass
+// that consumes them:
+//   pass 1 (over m  -> k1):  x_m  * c1^m ,  c1 = exp(i*pi/16)              (compile-time)
+//   pass 2 (over l2 -> k2):  x_l2 * c2^l2,  c2 = exp(i*pi*(1-4*k1)/128)    (8 values, LDS table)
+//   pass 3 (over l1 -> k3):  x_l1 * c3^l1,  c3 = exp(i*pi*(1-4*kap)/1024)  (kap = k1+8*k2 = per lane)
+// and  sum_m x_m c^m W8^(mk)  is a DFT-8 evaluated at the points c*W8^k ("shifted DFT-8"): a
+// radix-2 decimation-in-time network whose twelve butterflies (a, b) -> (a + w*b, a - w*b) carry the
+// twiddles w in {c^4; c^2, -i*c^2; c, c*W8, -i*c, -i*c*W8} and cost six FMAs each
+// (X = a + w*b: four, Y = 2a - X: two).  216 f64 instructions per forward transform (it was 244 with
+// separate twist / twiddle multiplies) and no twiddle-table read in passes 1 and 3.
+//
+// Forward, lane l, slot m holds z[l+64m]:
+//   pass 1 -> transpose A: (k1; l=l1+8*l2) -> lane k1*8+l1, slot l2
+//   pass 2 -> transpose B: (k1,l1; k2)     -> lane k1*8+k2, slot l1
+//   pass 3 -> lane mu, slot s holds bin k = (mu>>3) + 8*(mu&7) + 64*s
 //           = unscaled DFT_512 of the twisted fold (the reference stores 2x that).
-// The inverse is the exact mirror (decimation in time) and consumes that same
-// bin order, so no bit-reversal pass exists anywhere: the bootstrapping key is
-// permuted into this order once at upload.
+// The inverse walks the same index map backwards (conjugate kernels) and consumes that same bin
+// order, so no bit-reversal pass exists anywhere: the bootstrapping key is permuted into this order
+// once at upload.  Its twiddles are pre-twiddles of passes 2 and 3 in the same way; what cannot be
+// folded is the un-twist exp(-i*pi*(l+64m)/N), which sits on the OUTPUT index: its lane part G(l)
+// rides on the first butterfly stage of pass 3 (one extra complex multiply per butterfly), its slot
+// part exp(-i*pi*m/16) is seven constant multiplies at the end.
 //
 // LDS tile: 8 planes of 72 complex (stride padded from 64 so that both
 // transposes are bank-conflict free for ds_read_b128 / ds_write_b128).
 #pragma once
+#ifndef TFHE_FFT_HOST_EMU  // tests/cpp/test_fft_host.cpp supplies double2 / fma and empty qualifiers
 #include <hip/hip_runtime.h>
+#endif
 #include <stdint.h>
 
 namespace tfhe {
@@ -54,34 +66,63 @@ __device__ constexpr double kCmIm[8] = {0.0,
                                         0.92387953251128675612818318939679,
                                         0.98078528040323044912618223613424};
 
-// Per-lane twiddles, loaded once per kernel from the context's table
-// (computed on the host in long double): tw[0..511] = T1[k1][lane] as
-// [k1*64+lane], tw[512..575] = T2[k2][l1] as [512 + k2*8 + l1].
-//
-// T1 (lane-dependent, 8 complex) stays in registers for the whole kernel; T2 has only
-// 64 distinct values, so it sits in a 1 KiB LDS table read as it is used -- that frees
-// 28 VGPRs, which is what lets the key-row prefetch fit beside two waves per SIMD.
+// Twiddle table of the context (computed on the host in long double, tfhe_hip.hip make_twiddles):
+//   [0   .. 255]  forward pass 3, per lane:  [q*64 + lane], q = 0..3 : c3^4, c3^2, c3, c3*W8
+//                 with c3 = exp(i*pi*(1-4*kap)/1024), kap = (lane>>3) + 8*(lane&7)
+//   [256 .. 575]  inverse pass 3, per lane:  [256 + q*64 + lane], q = 0..4 : G, G*c^4, c^2, c, c*conj(W8)
+//                 with c = exp(2*pi*i*lane/512), G = exp(-i*pi*lane/1024)
+//   [576 .. 639]  the 1 KiB LDS table: forward pass 2 [q*8 + k1] (c2^4, c2^2, c2, c2*W8) then
+//                 inverse pass 2 [32 + q*8 + l1] (c^4, c^2, c, c*conj(W8) with c = exp(2*pi*i*l1/64))
+// The per-lane constants (36 VGPRs) stay in registers for the whole kernel; the pass-2 constants
+// have only 8 distinct values per entry and are read from LDS as they are used.
+constexpr int kTwEntries = 640;
 constexpr int kT2Bytes = 64 * 16;
 struct Twiddles {
-  double t1re[8], t1im[8];
-  const double2 *t2;  // LDS: [k2*8 + l1]
+  double f3[8];   // forward pass 3: (re, im) x {c^4, c^2, c, c*W8}
+  double i3[10];  // inverse pass 3: (re, im) x {G, G*c^4, c^2, c, c*conj(W8)}
+  const double2 *t2;
   __device__ __forceinline__ void load(const double2 *__restrict__ tw, double2 *t2_lds, int lane) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      double2 a = tw[k * 64 + lane];
-      t1re[k] = a.x;
-      t1im[k] = a.y;
+    for (int q = 0; q < 4; ++q) {
+      double2 a = tw[q * 64 + lane];
+      f3[2 * q] = a.x;
+      f3[2 * q + 1] = a.y;
     }
-    t2_lds[lane] = tw[512 + lane];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      double2 a = tw[256 + q * 64 + lane];
+      i3[2 * q] = a.x;
+      i3[2 * q + 1] = a.y;
+    }
+    t2_lds[lane] = tw[576 + lane];
     t2 = t2_lds;
     __syncthreads();
   }
+  // The inverse-pass-3 constants again, from the (cache-resident, 10 KiB) table: a kernel that runs
+  // long forward phases between its inverse transforms calls this just before them with an offset the
+  // compiler cannot see through (always 0), so the 20 registers are live only across the inverse
+  // transforms instead of the whole kernel.
+  __device__ __forceinline__ void reload_i3(const double2 *__restrict__ tw, int lane, int opaque_zero) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      double2 a = tw[256 + q * 64 + lane + opaque_zero];
+      i3[2 * q] = a.x;
+      i3[2 * q + 1] = a.y;
+    }
+  }
+  __device__ __forceinline__ void reload_f3(const double2 *__restrict__ tw, int lane, int opaque_zero) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double2 a = tw[q * 64 + lane + opaque_zero];
+      f3[2 * q] = a.x;
+      f3[2 * q + 1] = a.y;
+    }
+  }
 };
 
-// In-register 8-point DFT.  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
+// Plain in-register 8-point DFT (no pre-twiddle).  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
 // The two 1/sqrt2 twiddles are not applied where they arise: their common factor H is
-// carried to the last stage and folded into its add/sub as FMAs (X = b +- H*q), which
-// removes the four H multiplies per butterfly.
+// carried to the last stage and folded into its add/sub as FMAs (X = b +- H*q).  52 instructions.
 template <bool INV>
 __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
   constexpr double H = 0.70710678118654752440084436210485;
@@ -143,27 +184,93 @@ __device__ __forceinline__ void cmul(double &xr, double &xi, double wr, double w
   xi = i;
 }
 
+// Radix-2 decimation-in-time butterfly with its twiddle folded in: (a, b) <- (a + w*b, a - w*b).
+// X = a + w*b is two chained FMAs per component, Y = 2a - X one: six instructions, twiddle included.
+__device__ __forceinline__ void bfly(double &ar, double &ai, double &br, double &bi, double wr, double wi) {
+  const double xr = fma(-wi, bi, fma(wr, br, ar));
+  const double xi = fma(wi, br, fma(wr, bi, ai));
+  br = fma(2.0, ar, -xr);
+  bi = fma(2.0, ai, -xi);
+  ar = xr;
+  ai = xi;
+}
+
+// Shifted DFT-8:  X_k = sum_m x_m * (c * W8^k)^m,  W8 = exp(-2*pi*i/8) (INV: conjugate),
+// from the four constants c^4, c^2, c, c*W8 (INV: c*conj(W8)).  With SCALE the inputs are first
+// multiplied by g: the caller passes g and g*c^4 (the factor only has to reach the `a` operand of the
+// first stage; the `b` operand gets it through the twiddle).  72 instructions (88 with SCALE).
+template <bool INV, bool SCALE = false>
+__device__ __forceinline__ void sdft8(double (&re)[8], double (&im)[8], double c4r, double c4i, double c2r,
+                                      double c2i, double c1r, double c1i, double cwr, double cwi,
+                                      double gr = 1.0, double gi = 0.0) {
+  if (SCALE) {
+    cmul<false>(re[0], im[0], gr, gi);
+    cmul<false>(re[2], im[2], gr, gi);
+    cmul<false>(re[1], im[1], gr, gi);
+    cmul<false>(re[3], im[3], gr, gi);
+  }
+  // stage 1: (x0,x4) (x2,x6) (x1,x5) (x3,x7), twiddle c^4
+  bfly(re[0], im[0], re[4], im[4], c4r, c4i);
+  bfly(re[2], im[2], re[6], im[6], c4r, c4i);
+  bfly(re[1], im[1], re[5], im[5], c4r, c4i);
+  bfly(re[3], im[3], re[7], im[7], c4r, c4i);
+  // stage 2: twiddles c^2 and (-+i)*c^2      (-i*w = (wi, -wr);  +i*w = (-wi, wr))
+  bfly(re[0], im[0], re[2], im[2], c2r, c2i);
+  bfly(re[1], im[1], re[3], im[3], c2r, c2i);
+  if (!INV) {
+    bfly(re[4], im[4], re[6], im[6], c2i, -c2r);
+    bfly(re[5], im[5], re[7], im[7], c2i, -c2r);
+  } else {
+    bfly(re[4], im[4], re[6], im[6], -c2i, c2r);
+    bfly(re[5], im[5], re[7], im[7], -c2i, c2r);
+  }
+  // stage 3: twiddles c, c*W8, (-+i)*c, (-+i)*c*W8
+  bfly(re[0], im[0], re[1], im[1], c1r, c1i);
+  bfly(re[4], im[4], re[5], im[5], cwr, cwi);
+  if (!INV) {
+    bfly(re[2], im[2], re[3], im[3], c1i, -c1r);
+    bfly(re[6], im[6], re[7], im[7], cwi, -cwr);
+  } else {
+    bfly(re[2], im[2], re[3], im[3], -c1i, c1r);
+    bfly(re[6], im[6], re[7], im[7], -cwi, cwr);
+  }
+  // registers now hold X0 X4 X2 X6 X1 X5 X3 X7 -> natural order (a renaming, no instructions)
+  const double r1 = re[4], i1 = im[4], r3 = re[6], i3 = im[6], r4 = re[1], i4 = im[1], r6 = re[3], i6 = im[3];
+  re[1] = r1; im[1] = i1;
+  re[3] = r3; im[3] = i3;
+  re[4] = r4; im[4] = i4;
+  re[6] = r6; im[6] = i6;
+}
+
 // LDS hand-off WITHIN one wavefront: orders this wave's LDS writes before its later LDS reads of
 // other lanes' data.  LDS operations of a wave execute in program order, so the hardware needs no
 // barrier; what is needed is that the compiler keeps the order (memory clobber) and that pending
 // reads have returned before their registers are reused (lgkmcnt).  It involves no other wave, so
 // the same FFT code serves one-wave workgroups and the multi-wave latency kernel.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// Compiler-only ordering point for LDS traffic: the hardware keeps a wave's LDS operations in program
+// order, so a write may follow the reads of the same tile without a wait; the compiler's own
+// s_waitcnt protects the registers.
+__device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
 
-// Forward transform.  In: re/im[m] = fold of coefficients (l+64m, l+64m+512),
-// NOT yet twisted.  Out: re/im[s] = bin (mu>>3)+8*(mu&7)+64*s, unscaled.
-__device__ __forceinline__ void fft_forward(double (&re)[8], double (&im)[8], const Twiddles &tw,
-                                            double2 *tile, int lane) {
-#pragma unroll
-  for (int m = 1; m < 8; ++m) cmul<false>(re[m], im[m], kCmRe[m], kCmIm[m]);
-  dft8<false>(re, im);
-#pragma unroll
-  for (int k = 0; k < 8; ++k) cmul<false>(re[k], im[k], tw.t1re[k], tw.t1im[k]);
-  // transpose A: write (k1, l) at k1*72 + l ; read lane (k1', l1) slot l2 at k1'*72 + l1 + 8*l2
-  wave_lds_sync();  // previous readers of the tile are done
+// compile-time constants of pass 1: c1 = exp(i*pi/16): c1^4 = exp(i*pi/4), c1^2 = exp(i*pi/8),
+// c1*W8 = exp(-3*i*pi/16)
+constexpr double kP1c4 = 0.70710678118654752440084436210485;
+
+// Timing-only ablation (results wrong by construction): TFHE_ABL_NOLDS removes the transposes.
+#ifndef TFHE_ABL_NOLDS
+#define TFHE_ABL_NOLDS 0
+#endif
+// ---- the two transposes, as separable halves so that two transforms can be interleaved ---------
+// A: write (k1, l) at k1*72 + l ; read lane (k1', l1) slot l2 at k1'*72 + l1 + 8*l2
+// B: write (k1, k2, l1) at k1*72 + k2*9 + l1 ; read lane (k1, k2') slot l1 at k1*72 + k2'*9 + l1
+__device__ __forceinline__ void tpA_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
 #pragma unroll
   for (int k = 0; k < 8; ++k) tile[k * kPlane + lane] = make_double2(re[k], im[k]);
-  wave_lds_sync();
+}
+__device__ __forceinline__ void tpA_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -171,24 +278,95 @@ __device__ __forceinline__ void fft_forward(double (&re)[8], double (&im)[8], co
     re[s] = v.x;
     im[s] = v.y;
   }
-  dft8<false>(re, im);
-#pragma unroll
-  for (int k = 1; k < 8; ++k) {
-    const double2 w = tw.t2[k * 8 + lo];
-    cmul<false>(re[k], im[k], w.x, w.y);
-  }
-  // transpose B: write (k1, k2, l1) at k1*72 + k2*9 + l1 ; read lane (k1, k2') slot l1
-  wave_lds_sync();
+}
+__device__ __forceinline__ void tpB_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+  const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int k = 0; k < 8; ++k) tile[hi * kPlane + k * 9 + lo] = make_double2(re[k], im[k]);
-  wave_lds_sync();
+}
+__device__ __forceinline__ void tpB_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+  const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     double2 v = tile[hi * kPlane + lo * 9 + s];
     re[s] = v.x;
     im[s] = v.y;
   }
-  dft8<false>(re, im);
+}
+// the inverse transposes are the same maps with the roles of write and read exchanged
+__device__ __forceinline__ void tpBi_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+  const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) tile[hi * kPlane + lo * 9 + s] = make_double2(re[s], im[s]);
+}
+__device__ __forceinline__ void tpBi_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+  const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double2 v = tile[hi * kPlane + k * 9 + lo];
+    re[k] = v.x;
+    im[k] = v.y;
+  }
+}
+__device__ __forceinline__ void tpAi_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+  const int hi = lane >> 3, lo = lane & 7;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) tile[hi * kPlane + lo + 8 * s] = make_double2(re[s], im[s]);
+}
+__device__ __forceinline__ void tpAi_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
+  if (TFHE_ABL_NOLDS) return;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double2 v = tile[k * kPlane + lane];
+    re[k] = v.x;
+    im[k] = v.y;
+  }
+}
+
+// ---- the passes --------------------------------------------------------------------------------
+__device__ __forceinline__ void fwd_pass1(double (&re)[8], double (&im)[8]) {
+  sdft8<false>(re, im, kP1c4, kP1c4, kCmRe[2], kCmIm[2], kCmRe[1], kCmIm[1], kCmRe[3], -kCmIm[3]);
+}
+__device__ __forceinline__ void fwd_pass2(double (&re)[8], double (&im)[8], const Twiddles &tw, int lane) {
+  const int hi = lane >> 3;
+  const double2 c4 = tw.t2[hi], c2 = tw.t2[8 + hi], c1 = tw.t2[16 + hi], cw = tw.t2[24 + hi];
+  sdft8<false>(re, im, c4.x, c4.y, c2.x, c2.y, c1.x, c1.y, cw.x, cw.y);
+}
+__device__ __forceinline__ void fwd_pass3(double (&re)[8], double (&im)[8], const Twiddles &tw) {
+  sdft8<false>(re, im, tw.f3[0], tw.f3[1], tw.f3[2], tw.f3[3], tw.f3[4], tw.f3[5], tw.f3[6], tw.f3[7]);
+}
+__device__ __forceinline__ void inv_pass2(double (&re)[8], double (&im)[8], const Twiddles &tw, int lane) {
+  const int lo = lane & 7;
+  const double2 c4 = tw.t2[32 + lo], c2 = tw.t2[40 + lo], c1 = tw.t2[48 + lo], cw = tw.t2[56 + lo];
+  sdft8<true>(re, im, c4.x, c4.y, c2.x, c2.y, c1.x, c1.y, cw.x, cw.y);
+}
+__device__ __forceinline__ void inv_pass3(double (&re)[8], double (&im)[8], const Twiddles &tw) {
+  sdft8<true, true>(re, im, tw.i3[2], tw.i3[3], tw.i3[4], tw.i3[5], tw.i3[6], tw.i3[7], tw.i3[8], tw.i3[9],
+                    tw.i3[0], tw.i3[1]);
+#pragma unroll
+  for (int m = 1; m < 8; ++m) cmul<true>(re[m], im[m], kCmRe[m], kCmIm[m]);
+}
+
+// Forward transform.  In: re/im[m] = fold of coefficients (l+64m, l+64m+512),
+// NOT yet twisted.  Out: re/im[s] = bin (mu>>3)+8*(mu&7)+64*s, unscaled.
+__device__ __forceinline__ void fft_forward(double (&re)[8], double (&im)[8], const Twiddles &tw,
+                                            double2 *tile, int lane) {
+  fwd_pass1(re, im);
+  wave_lds_order();  // previous readers of the tile were issued earlier: LDS executes in order
+  tpA_write(re, im, tile, lane);
+  wave_lds_order();
+  tpA_read(re, im, tile, lane);
+  fwd_pass2(re, im, tw, lane);
+  wave_lds_order();
+  tpB_write(re, im, tile, lane);
+  wave_lds_order();
+  tpB_read(re, im, tile, lane);
+  fwd_pass3(re, im, tw);
 }
 
 // Inverse transform (mirror).  In: bins in the forward output order.
@@ -197,43 +375,78 @@ __device__ __forceinline__ void fft_forward(double (&re)[8], double (&im)[8], co
 // 1/512 in :136) is folded into the operands by the caller.
 __device__ __forceinline__ void fft_inverse(double (&re)[8], double (&im)[8], const Twiddles &tw,
                                             double2 *tile, int lane) {
-  const int hi = lane >> 3, lo = lane & 7;
   dft8<true>(re, im);  // over k3 -> l1
-  wave_lds_sync();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) tile[hi * kPlane + lo * 9 + s] = make_double2(re[s], im[s]);
-  wave_lds_sync();
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    double2 v = tile[hi * kPlane + k * 9 + lo];
-    re[k] = v.x;
-    im[k] = v.y;
-  }
-#pragma unroll
-  for (int k = 1; k < 8; ++k) {
-    const double2 w = tw.t2[k * 8 + lo];
-    cmul<true>(re[k], im[k], w.x, w.y);
-  }
-  dft8<true>(re, im);  // over k2 -> l2
-  wave_lds_sync();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) tile[hi * kPlane + lo + 8 * s] = make_double2(re[s], im[s]);
-  wave_lds_sync();
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    double2 v = tile[k * kPlane + lane];
-    re[k] = v.x;
-    im[k] = v.y;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; ++k) cmul<true>(re[k], im[k], tw.t1re[k], tw.t1im[k]);
-  dft8<true>(re, im);  // over k1 -> m
-#pragma unroll
-  for (int m = 1; m < 8; ++m) cmul<true>(re[m], im[m], kCmRe[m], kCmIm[m]);
+  wave_lds_order();
+  tpBi_write(re, im, tile, lane);
+  wave_lds_order();
+  tpBi_read(re, im, tile, lane);
+  inv_pass2(re, im, tw, lane);  // over k2 -> l2
+  wave_lds_order();
+  tpAi_write(re, im, tile, lane);
+  wave_lds_order();
+  tpAi_read(re, im, tile, lane);
+  inv_pass3(re, im, tw);  // over k1 -> m, un-twist
 }
 
-// f64::round (half away from zero) then `as i64 as u32` (klemsa.rs:145-146):
-// low 32 bits of the rounded integer, exact for |x| < 2^63.
+// Two independent inverse transforms interleaved through ONE tile: while the transpose of one is on
+// its way through the LDS the other's butterflies issue, so a wave covers its own LDS round trips.
+// Legal on one tile because a wave's LDS operations execute in program order: y's writes cannot
+// overtake x's reads.
+__device__ __forceinline__ void fft_inverse2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8],
+                                             const Twiddles &tw, double2 *tile, int lane) {
+  dft8<true>(xr, xi);
+  wave_lds_order();
+  tpBi_write(xr, xi, tile, lane);
+  wave_lds_order();
+  tpBi_read(xr, xi, tile, lane);
+  dft8<true>(yr, yi);  // covers x's round trip
+  wave_lds_order();
+  tpBi_write(yr, yi, tile, lane);
+  wave_lds_order();
+  tpBi_read(yr, yi, tile, lane);
+  inv_pass2(xr, xi, tw, lane);  // covers y's
+  wave_lds_order();
+  tpAi_write(xr, xi, tile, lane);
+  wave_lds_order();
+  tpAi_read(xr, xi, tile, lane);
+  inv_pass2(yr, yi, tw, lane);
+  wave_lds_order();
+  tpAi_write(yr, yi, tile, lane);
+  wave_lds_order();
+  tpAi_read(yr, yi, tile, lane);
+  inv_pass3(xr, xi, tw);
+  inv_pass3(yr, yi, tw);
+}
+
+// Two independent forward transforms interleaved the same way.
+__device__ __forceinline__ void fft_forward2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8],
+                                             const Twiddles &tw, double2 *tile, int lane) {
+  fwd_pass1(xr, xi);
+  wave_lds_order();
+  tpA_write(xr, xi, tile, lane);
+  wave_lds_order();
+  tpA_read(xr, xi, tile, lane);
+  fwd_pass1(yr, yi);
+  wave_lds_order();
+  tpA_write(yr, yi, tile, lane);
+  wave_lds_order();
+  tpA_read(yr, yi, tile, lane);
+  fwd_pass2(xr, xi, tw, lane);
+  wave_lds_order();
+  tpB_write(xr, xi, tile, lane);
+  wave_lds_order();
+  tpB_read(xr, xi, tile, lane);
+  fwd_pass2(yr, yi, tw, lane);
+  wave_lds_order();
+  tpB_write(yr, yi, tile, lane);
+  wave_lds_order();
+  tpB_read(yr, yi, tile, lane);
+  fwd_pass3(xr, xi, tw);
+  fwd_pass3(yr, yi, tw);
+}
+
+#ifndef TFHE_FFT_HOST_EMU
+// `as i64 as u32` of f64::round (klemsa.rs:145-146): low 32 bits of the rounded integer.
 //
 // FAST: valid when |x| < 2^51 is guaranteed (the host checks
 // 2l * N * (Bg/2) * 2^31 < 2^51, true for l=3,bgbit=6): adding 1.5*2^52 leaves
@@ -254,6 +467,19 @@ __device__ __forceinline__ uint32_t round_to_torus(double x) {
     const double v = fma(q, -0x1p32, x);
     return (uint32_t)__double2loint(v + 0x1.8p52);
   }
+}
+
+#endif  // TFHE_FFT_HOST_EMU
+
+// f64::round exactly as the reference's FFTProcessor::fft does it (klemsa.rs:145-146): half away
+// from zero, then `as i64 as u32`.  Used by the stage entry points (tfhe_hip_batch_fft / _poly_mul),
+// whose caller-supplied spectra may land on exact .5 ties; valid for |x| < 2^63.
+__device__ __forceinline__ uint32_t round_half_away_to_torus(double x) {
+  const double q = rint(x * 0x1p-32);   // multiple of 2^32 to drop (its own ties are irrelevant: |v| <= 2^31 either way)
+  const double v = fma(q, -0x1p32, x);  // exact: x - q*2^32
+  double r = rint(v);                   // ties to even ...
+  if (fabs(v - r) == 0.5) r = v + copysign(0.5, x);  // ... moved away from zero (the sign is x's, not v's)
+  return (uint32_t)(long long)r;
 }
 
 // bin held by (lane mu, slot s) after fft_forward

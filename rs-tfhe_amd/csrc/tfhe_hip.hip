@@ -20,6 +20,7 @@
 #include "blind_rotate.hpp"
 #include "key_switch.hpp"
 #include "keygen.hpp"
+#include "twiddles_host.hpp"
 
 using namespace tfhe;
 
@@ -62,7 +63,37 @@ struct tfhe_hip_ctx {
   uint64_t bootstraps = 0;
   hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
   bool scratch_owned = false;
+  // device diagnostics: [0] shader cycles, [1] constant-rate ticks (both summed over blind-rotate
+  // workgroups while profiling is on), [2] error flag raised by kernels (bad gate code)
+  unsigned long long *d_diag = nullptr;
+  int rtc_khz = 100000;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
 };
+
+namespace {
+// The HIP current device is per host thread and shared with every other library in the process
+// (torch included): set ours for the duration of a call and put the caller's back.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+}  // namespace
+
+// every entry point: serialise on the context, make its device current, restore the caller's on return
+#define ENTER(ctx)                                                                     \
+  std::lock_guard<std::mutex> lk_((ctx)->mu);                                          \
+  DeviceGuard dg_((ctx)->device);                                                      \
+  if (dg_.err != hipSuccess) {                                                         \
+    (ctx)->err = std::string("hipSetDevice: ") + hipGetErrorString(dg_.err);           \
+    return TFHE_HIP_EHIP;                                                              \
+  }
 
 #define HIPCHK(ctx, call)                                                                   \
   do {                                                                                      \
@@ -187,6 +218,12 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.out_trlwe = out_trlwe;
   A.out_lv1 = out_lv1;
   A.out_ext2 = out_ext2;
+  A.clk = ctx->profiling ? ctx->d_diag : nullptr;
+  A.err_flag = reinterpret_cast<uint32_t *>(ctx->d_diag + 2);
+  // sample_extract_index_2 reads a[n - i] of an N-coefficient polynomial (trlwe.rs:122-136): the reference
+  // indexes out of bounds (panics) for n > N; refuse instead of reading the b half of the accumulator
+  if (out_ext2 && ctx->P.n > kN)
+    return fail(ctx, TFHE_HIP_EINVAL, "bootstrap without key switch needs n <= N (sample_extract_index_2)");
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
   // small batches: one workgroup of 2l waves per ciphertext (latency kernel)
   if (ctx->br_wide && count <= ctx->wide_max) {
@@ -392,26 +429,6 @@ int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
   return TFHE_HIP_OK;
 }
 
-void make_twiddles(std::vector<double2> &tw) {
-  tw.resize(576);
-  const long double pi = 3.14159265358979323846264338327950288L;
-  for (int k1 = 0; k1 < 8; ++k1)
-    for (int l = 0; l < 64; ++l) {
-      // T1[l][k1] = exp(i*pi*l*(1-4*k1)/1024)
-      long e = ((long)l * (1 - 4 * k1)) % 2048;
-      if (e < 0) e += 2048;
-      long double ang = pi * (long double)e / 1024.0L;
-      tw[k1 * 64 + l] = make_double2((double)cosl(ang), (double)sinl(ang));
-    }
-  for (int k2 = 0; k2 < 8; ++k2)
-    for (int l1 = 0; l1 < 8; ++l1) {
-      // T2[l1][k2] = exp(-2*pi*i*l1*k2/64)
-      int e = (l1 * k2) % 64;
-      long double ang = -2.0L * pi * (long double)e / 64.0L;
-      tw[512 + k2 * 8 + l1] = make_double2((double)cosl(ang), (double)sinl(ang));
-    }
-}
-
 }  // namespace
 
 // =============================================================================
@@ -455,9 +472,14 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     delete ctx;
     return TFHE_HIP_EHIP;
   };
-  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  DeviceGuard dg(device);
+  if (dg.err != hipSuccess) return bail("hipSetDevice", dg.err);
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", e);
+  if ((e = hipMalloc((void **)&ctx->d_diag, 32)) != hipSuccess) return bail("hipMalloc diagnostics", e);
+  if ((e = hipMemset(ctx->d_diag, 0, 32)) != hipSuccess) return bail("hipMemset diagnostics", e);
+  if (hipDeviceGetAttribute(&ctx->rtc_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || ctx->rtc_khz <= 0)
+    ctx->rtc_khz = 100000;
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
   ctx->num_cus = prop.multiProcessorCount;
@@ -487,8 +509,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
 
 void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   if (!ctx) return;
-  (void)hipSetDevice(ctx->device);
+  DeviceGuard dg(ctx->device);
+  if (ctx->scratch_owned && ctx->scratch_owner != ctx->stream) (void)hipStreamSynchronize(ctx->scratch_owner);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->d_diag) (void)hipFree(ctx->d_diag);
   for (auto &p : ctx->ev_br) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
@@ -511,9 +535,13 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
 int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
                             uint32_t decomp_offset, const uint32_t *testvec) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (!bsk || !ksk || !testvec) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // Work queued earlier on the caller's streams (*_dev entry points) may still be reading the key this
+  // call is about to overwrite: drain it first.
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
   const tfhe_hip_params &P = ctx->P;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
   const size_t bsk_bytes = polys * kN * sizeof(double);
@@ -559,10 +587,14 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
 int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
                            double alpha_bsk, uint64_t seed) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (!key_lv0 || !key_lv1) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
   if (!(alpha_ksk >= 0.0) || !(alpha_bsk >= 0.0)) return fail(ctx, TFHE_HIP_EINVAL, "negative noise parameter");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // Work queued earlier on the caller's streams (*_dev entry points) may still be reading the key this
+  // call is about to overwrite: drain it first.
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
   const tfhe_hip_params &P = ctx->P;
   const int base = 1 << P.basebit;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
@@ -604,9 +636,8 @@ int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uin
 int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
                               uint32_t *testvec) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const tfhe_hip_params &P = ctx->P;
   const int base = 1 << P.basebit;
   if (bsk) {
@@ -636,20 +667,18 @@ int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uin
 int tfhe_hip_batch_gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
                             uint32_t *out, size_t count, void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!a || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return gate_dev(ctx, gate, a, b, out, count, pick(ctx, stream));
 }
 
 int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                    uint32_t *out, size_t count, void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!gates || !a || !b || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return gates_mixed_dev(ctx, gates, a, b, out, count, pick(ctx, stream));
 }
 
@@ -657,10 +686,9 @@ int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const ui
                                  int per_ct, int keyswitch, uint32_t *out, size_t count,
                                  void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!in || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return bootstrap_dev(ctx, in, testvec, per_ct, keyswitch, out, count, pick(ctx, stream));
 }
 
@@ -668,9 +696,8 @@ int tfhe_hip_batch_tlwe_lincomb_dev(tfhe_hip_ctx *ctx, uint32_t ca, const uint32
                                     const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count,
                                     void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (count && (!a || !out || (cb && !b))) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return lincomb_dev(ctx, GatePrep{ca, cb, cconst}, a, b, out, count, pick(ctx, stream));
 }
 
@@ -679,10 +706,9 @@ int tfhe_hip_batch_lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, uint32_t ca, const u
                                          int per_ct, int keyswitch, uint32_t *out, size_t count,
                                          void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!a || !out || (cb && !b))) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return lincomb_bootstrap_dev(ctx, GatePrep{ca, cb, cconst}, a, cb ? b : nullptr, testvec, per_ct, keyswitch, out,
                                count, pick(ctx, stream));
 }
@@ -690,10 +716,9 @@ int tfhe_hip_batch_lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, uint32_t ca, const u
 int tfhe_hip_batch_blind_rotate_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                     uint32_t *out_trlwe, size_t count, void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!in || !out_trlwe)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   GatePrep gp;
   gate_prep(TFHE_HIP_COPY, gp);
   return launch_blind_rotate(ctx, pick(ctx, stream), in, nullptr, gp, testvec, 0, count, out_trlwe,
@@ -703,10 +728,9 @@ int tfhe_hip_batch_blind_rotate_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const
 int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
                            const uint32_t *c, uint32_t *out, size_t count, void *stream) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count && (!a || !b || !c || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   return mux_dev(ctx, naive, a, b, c, out, count, pick(ctx, stream));
 }
 
@@ -715,13 +739,12 @@ int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, cons
 int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
                         uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   GatePrep gp;
   if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
   if (!a || !out || (gp.cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   if (gp.cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -733,13 +756,12 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
 int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!gates || !a || !b || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   for (size_t i = 0; i < count; ++i)
     if (gates[i] > TFHE_HIP_COPY) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -753,11 +775,10 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
 int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                              int per_ct, int keyswitch, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!in || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, in, bytes));
   const uint32_t *d_tv = nullptr;
@@ -773,10 +794,9 @@ int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32
 int tfhe_hip_batch_tlwe_lincomb(tfhe_hip_ctx *ctx, uint32_t ca, const uint32_t *a, uint32_t cb,
                                 const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (count == 0) return TFHE_HIP_OK;
   if (!a || !out || (cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   if (cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -790,11 +810,10 @@ int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint3
                                      const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
                                      int per_ct, int keyswitch, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!a || !out || (cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   if (cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -813,11 +832,10 @@ int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint3
 int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                 uint32_t *out_trlwe, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!in || !out_trlwe) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, in, count * (size_t)(ctx->P.n + 1) * 4));
   const uint32_t *d_tv = nullptr;
   if (testvec) {
@@ -836,11 +854,10 @@ int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uin
 int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
                        const uint32_t *c, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!a || !b || !c || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -856,13 +873,12 @@ int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const ui
 int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
                                     const int32_t *bsk_index, uint32_t *trlwe_out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!trlwe_in || !bsk_index || !trlwe_out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   for (size_t i = 0; i < count; ++i)
     if (bsk_index[i] < 0 || bsk_index[i] >= ctx->P.n) return fail(ctx, TFHE_HIP_EINVAL, "bsk_index out of range");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)2 * kN * 4;
   CHK(to_dev(ctx, ctx->h_a, trlwe_in, bytes));
   CHK(to_dev(ctx, ctx->h_idx, bsk_index, count * 4));
@@ -880,11 +896,10 @@ int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
 
 int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, int k, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (k < 0 || k >= kN) return fail(ctx, TFHE_HIP_EINVAL, "extraction index out of range");
   if (count == 0) return TFHE_HIP_OK;
   if (!trlwe || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, trlwe, count * (size_t)2 * kN * 4));
   const size_t obytes = count * (size_t)(kN + 1) * 4;
   CHK(ensure(ctx, ctx->h_out, obytes));
@@ -896,11 +911,10 @@ int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, int 
 
 int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_lv1, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!tlwe_lv1 || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, tlwe_lv1, count * (size_t)(kN + 1) * 4));
   const size_t obytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(ensure(ctx, ctx->h_out, obytes));
@@ -910,10 +924,9 @@ int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_l
 
 int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (count == 0) return TFHE_HIP_OK;
   if (!res || !src) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 4));
   CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 8));
   hipLaunchKernelGGL(k_ifft, dim3((unsigned)count), dim3(64), kStageLdsBytes, ctx->stream,
@@ -924,10 +937,9 @@ int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, siz
 
 int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (count == 0) return TFHE_HIP_OK;
   if (!res || !src) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   CHK(to_dev(ctx, ctx->h_a, src, count * (size_t)kN * 8));
   CHK(ensure(ctx, ctx->h_out, count * (size_t)kN * 4));
   hipLaunchKernelGGL(k_fft, dim3((unsigned)count), dim3(64), kStageLdsBytes, ctx->stream,
@@ -938,10 +950,9 @@ int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size
 
 int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a, const uint32_t *b, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
   if (count == 0) return TFHE_HIP_OK;
   if (!res || !a || !b) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = count * (size_t)kN * 4;
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
@@ -957,15 +968,15 @@ int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
 
 int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  ENTER(ctx);
+  if (enabled && !ctx->profiling) HIPCHK(ctx, hipMemsetAsync(ctx->d_diag, 0, 16, ctx->stream));
   ctx->profiling = enabled != 0;
   return TFHE_HIP_OK;
 }
 
 int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out) {
   if (!ctx || !out) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER(ctx);
   memset(out, 0, sizeof(*out));
   auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, double &ms, uint64_t &cnt) -> int {
     for (auto &p : v) {
@@ -987,11 +998,33 @@ int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out) {
   return TFHE_HIP_OK;
 }
 
+int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out) {
+  if (!ctx || !out) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpy(h, ctx->d_diag, 16, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemset(ctx->d_diag, 0, 16));
+  out->shader_cycles = h[0];
+  out->rtc_ticks = h[1];
+  out->rtc_mhz = ctx->rtc_khz / 1000.0;
+  out->shader_mhz = h[1] ? (double)h[0] / (double)h[1] * out->rtc_mhz : 0.0;
+  return TFHE_HIP_OK;
+}
+
 int tfhe_hip_synchronize(tfhe_hip_ctx *ctx) {
   if (!ctx) return TFHE_HIP_EINVAL;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ENTER(ctx);
+  if (ctx->scratch_owned && ctx->scratch_owner != ctx->stream) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
+  uint32_t flag = 0;
+  HIPCHK(ctx, hipMemcpy(&flag, ctx->d_diag + 2, 4, hipMemcpyDeviceToHost));
+  if (flag) {
+    HIPCHK(ctx, hipMemset(ctx->d_diag + 2, 0, 8));
+    return fail(ctx, TFHE_HIP_EINVAL, "a *_mixed_dev launch saw a gate code outside tfhe_hip_gate (treated as COPY)");
+  }
   return TFHE_HIP_OK;
 }
 

@@ -359,5 +359,12 @@ class Engine:
             "bootstraps": int(kt.bootstraps),
         }
 
+    def clock_sample(self) -> dict:
+        """Shader clock the blind-rotation kernel actually ran at (sampled while profiling is on)."""
+        cs = _capi.ClockSample()
+        self._chk(self._lib.tfhe_hip_get_clock_sample(self._ctx, C.byref(cs)))
+        return {"shader_mhz": cs.shader_mhz, "rtc_mhz": cs.rtc_mhz, "shader_cycles": int(cs.shader_cycles),
+                "rtc_ticks": int(cs.rtc_ticks)}
+
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))

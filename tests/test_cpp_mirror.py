@@ -14,6 +14,16 @@ def test_cpp_mirror_builds():
     assert os.path.exists(os.path.join(CPP, "build", "test_mirror"))
 
 
+def test_device_fft_algebra_on_host():
+    """fft512.hpp's passes / transposes / twiddle table, compiled for the CPU and driven in lock-step over
+    64 emulated lanes, equal the definition of KlemsaProcessor::ifft / fft (klemsa.rs:88-150) to 1e-14
+    relative, and the stage API's rounding is f64::round on exact ties (klemsa.rs:145-146)."""
+    subprocess.check_call(["make", "-C", CPP, "build/test_fft_host"])
+    r = subprocess.run([os.path.join(CPP, "build", "test_fft_host")], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "all checks passed" in r.stdout
+
+
 @pytest.mark.gpu
 def test_cpp_mirror_runs_on_gpu():
     exe = os.path.join(CPP, "build", "test_mirror")

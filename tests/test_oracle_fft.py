@@ -113,3 +113,40 @@ def test_reference_spqlios_cross_check(O, golden):
         assert signed_diff(ref, O.klemsa_poly_mul(a, b)) <= 1
     x = g["kat_klemsa_roundtrip"]
     assert signed_diff(O.ref_roundtrip(x), x) <= 1
+
+
+def test_reference_spqlios_external_product(O, keys128):
+    """A whole external product (trgsw.rs:77-116) assembled from the REFERENCE's own compiled code:
+    2l calls of Spqlios_poly_mul_1024 (spqlios-wrapper.cpp:33-40) per output polynomial, on the digits
+    orc_decomposition produces.  Holds orc_external_product_exact / _fft to real reference arithmetic
+    for the things a second restatement could share a slip on: the sign convention of the digits
+    (quirk Q3: stored as wrapped u32, read back as signed), which rows multiply which half
+    (rows 0..l-1 <- a, l..2l-1 <- b, trgsw.rs:99-106) and the a / b column order.
+    Tolerance: SPQLIOS truncates each product (fft_processor_spqlios.cpp:128-129): <= 1 LSB per
+    product, 2l products per coefficient."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    sk, ck = keys128
+    P = ck.params
+    rng = np.random.default_rng(21)
+    for i in (0, 7, 699):
+        t = rng.integers(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
+        dec = O.decomposition(t, P.l, P.bgbit, ck.decomposition_offset)
+        # digits are signed in [-Bg/2, Bg/2) once read as i32 (Q3)
+        d = dec.view(np.int32)
+        assert d.min() >= -(1 << (P.bgbit - 1)) and d.max() < (1 << (P.bgbit - 1))
+        out = np.zeros((2, N), np.uint32)
+        for r in range(2 * P.l):
+            for c in range(2):
+                out[c] += O.ref_poly_mul(ck.bootstrapping_key_time[i][r][c], dec[r])
+        exact = O.external_product_exact(ck.bootstrapping_key_time[i], t, P.l, P.bgbit, ck.decomposition_offset)
+        fft = O.external_product_fft(ck.bootstrapping_key[i], t, P.l, P.bgbit, ck.decomposition_offset)
+        assert signed_diff(out, exact) <= 2 * P.l
+        assert signed_diff(out, fft) <= 2 * P.l
+        # and the assembly is sensitive to what it is meant to pin: swapping the halves' rows or
+        # reading the digits unsigned lands far away
+        swapped = np.zeros((2, N), np.uint32)
+        for r in range(2 * P.l):
+            for c in range(2):
+                swapped[c] += O.ref_poly_mul(ck.bootstrapping_key_time[i][(r + P.l) % (2 * P.l)][c], dec[r])
+        assert signed_diff(swapped, exact) > (1 << 20)
