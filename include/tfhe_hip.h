@@ -119,8 +119,23 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
  * generated on the GPU straight into the context (no upload).  Needs the secret key, so it is a
  * client-side call.  key_lv0 [n], key_lv1 [N]: 0/1 words (src/key.rs:21-49).
  * alpha_ksk = tlwe_lv0.alpha (KSK_ALPHA, params.rs:468), alpha_bsk = tlwe_lv1.alpha (BSK_ALPHA,
- * :469).  The reference draws from an unseeded thread_rng; here `seed` fixes the key bit-for-bit
- * (counter-based Philox4x32-10), the distributions are the reference's. */
+ * :469).
+ *
+ * Randomness.  The reference draws every mask word and noise sample from an OS-seeded ChaCha thread_rng
+ * (tlwe.rs:38, trlwe.rs:36-41).  Here they are fixed positions of a ChaCha20 keystream (RFC 8439, 20 rounds)
+ * under a 256-bit generator key; the distributions are the reference's.  A published cloud key is only as
+ * secret as that generator key -- whoever can regenerate the noise solves the key rows for the secret key --
+ * so:
+ *   tfhe_hip_gen_cloud_key_secure    the generator key comes from getrandom(2).  USE THIS ONE.
+ *   tfhe_hip_gen_cloud_key_with_key  the caller supplies 32 bytes from its own CSPRNG (e.g. Rust's OsRng).
+ *   tfhe_hip_gen_cloud_key           TEST / BENCHMARK ONLY: a 64-bit seed is expanded into the generator key,
+ *                                    which makes the cloud key reproducible bit for bit and exactly as
+ *                                    guessable as the seed.  Never publish a key generated this way.
+ * The secret-key staging buffers on the device are zeroed before any of the three returns. */
+int tfhe_hip_gen_cloud_key_secure(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                  double alpha_ksk, double alpha_bsk);
+int tfhe_hip_gen_cloud_key_with_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                    double alpha_ksk, double alpha_bsk, const uint8_t rng_key[32]);
 int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
                            double alpha_ksk, double alpha_bsk, uint64_t seed);
 
@@ -128,6 +143,16 @@ int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uin
  * (any pointer may be NULL to skip that field).  load -> export is the identity. */
 int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
                               uint32_t *testvec);
+
+/* The context's cloud key as raw device buffers in the ENGINE layouts, for callers that
+ * replicate a key device to device themselves -- one process per GPU, where the pool's hipMemcpyPeer cannot reach:
+ * the owner of the key and every receiver call this (it allocates the buffers when the context has none yet),
+ * the bytes travel (RCCL broadcast, hipMemcpyPeer, IPC), and each receiver then calls
+ * tfhe_hip_adopt_cloud_key(ctx, decomp_offset of the owner).  The buffers stay owned by the context; while a
+ * receiver's buffers are being written it must not run batches.  Any out pointer may be NULL. */
+int tfhe_hip_cloud_key_buffers(tfhe_hip_ctx *ctx, void **bsk, size_t *bsk_bytes, void **ksk, size_t *ksk_bytes,
+                               void **testvec, size_t *testvec_bytes, uint32_t *decomp_offset);
+int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset);
 
 /* ---- the hot path, batched --------------------------------------------- */
 
@@ -273,6 +298,53 @@ int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
  * last *_dev call -- has finished.  Returns TFHE_HIP_EINVAL (and clears the condition) if a
  * tfhe_hip_batch_gates_mixed_dev launch since the last call met a gate code outside tfhe_hip_gate. */
 int tfhe_hip_synchronize(tfhe_hip_ctx *ctx);
+
+/* ---- several GPUs behind one handle --------------------------------------------------------------
+ * Replaces: the Rayon `par_map` the reference's batch functions run on
+ * (src/parallel/rayon_impl.rs:40-47, called from src/gates.rs:357-383, src/trgsw.rs:289-305): an
+ * order-preserving, embarrassingly parallel map over the ciphertexts of a slice under one shared read-only
+ * &CloudKey.  A pool is that map over devices: one context per entry of `devices` (an entry may repeat: two
+ * contexts on one GPU), the cloud key generated / uploaded once on the first device and replicated device to
+ * device in the engine layouts, the batch split contiguously (shard r of k = tfhe_hip_pool_shard), one host
+ * thread per shard, results written into the caller's output slice in input order.  No collective and no
+ * exchange between devices on the data path.  Pool calls are serialised per pool; a member context borrowed
+ * with tfhe_hip_pool_ctx() (for the *_dev entry points) must not be used while a pool call runs. */
+typedef struct tfhe_hip_pool tfhe_hip_pool;
+
+int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int ndev, tfhe_hip_pool **out);
+void tfhe_hip_pool_destroy(tfhe_hip_pool *pool);
+int tfhe_hip_pool_size(const tfhe_hip_pool *pool);
+tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *pool, int member);
+/* Text of the last failed pool call ("device D: ..."), or of the last failed create when pool == NULL. */
+const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *pool);
+/* [lo, hi) of shard `shard` of `nshards` over `count` items: contiguous, sizes differ by at most one, earlier
+ * shards take the remainder (the split every pool batch call uses). */
+void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_t *hi);
+
+/* Cloud key for every member: same arguments and meaning as the tfhe_hip_*_cloud_key calls above. */
+int tfhe_hip_pool_load_cloud_key(tfhe_hip_pool *pool, const double *bsk, const uint32_t *ksk, uint32_t decomp_offset,
+                                 const uint32_t *testvec);
+int tfhe_hip_pool_gen_cloud_key_secure(tfhe_hip_pool *pool, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                       double alpha_ksk, double alpha_bsk);
+int tfhe_hip_pool_gen_cloud_key_with_key(tfhe_hip_pool *pool, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                         double alpha_ksk, double alpha_bsk, const uint8_t rng_key[32]);
+int tfhe_hip_pool_gen_cloud_key(tfhe_hip_pool *pool, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                double alpha_ksk, double alpha_bsk, uint64_t seed); /* TEST / BENCHMARK ONLY */
+int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *pool, int member, double *bsk, uint32_t *ksk,
+                                   uint32_t *decomp_offset, uint32_t *testvec);
+
+/* The batched hot path over all members: same arguments and semantics as the single-context host entry
+ * points of the same name (gates.rs:352-547; gates.rs:157-199; bootstrap/{vanilla,lut}.rs; trgsw.rs:289-305). */
+int tfhe_hip_pool_batch_gate(tfhe_hip_pool *pool, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
+                             size_t count);
+int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *pool, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                    uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *pool, const uint32_t *in, const uint32_t *testvec, int per_ct,
+                                  int keyswitch, uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_mux(tfhe_hip_pool *pool, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c,
+                            uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_blind_rotate(tfhe_hip_pool *pool, const uint32_t *in, const uint32_t *testvec,
+                                     uint32_t *out_trlwe, size_t count);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,9 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for one tag on the GPU box:  bash profiles/collect.sh <tag> [bench args]
 # One --kernel-trace pass, then separate --pmc passes (never combined with traces), reduced to
-# gpurun_out/<tag>_kernel_stats.csv / <tag>_pmc.csv by summarize_rocpd.py; copy those into profiles/.
+# gpurun_out/<tag>_kernel_stats.csv / <tag>_pmc.csv by summarize_rocpd.py and to a gpurun_out/<tag>_pmc_roofline.json
+# entry (per-launch HBM bytes and issue fractions of the two kernels) by pmc_roofline.py; copy those into
+# profiles/ (the entry goes into profiles/pmc_roofline.json, which bench.py reads for `roofline.traffic`).
 tag=${1:?tag}; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/$tag
@@ -19,7 +21,8 @@ WRITE_SIZE
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
-TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr
+TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr
 LIST
 PROFILE_OUT="$R/gpurun_out" python3 profiles/summarize_rocpd.py "$tag" $(find "$O/trace" -name '*.db' | head -1) $(find "$O"/pmc* -name '*.db') > "$O/summary.txt" 2>&1
+python3 profiles/pmc_roofline.py "$R/gpurun_out/${tag}_pmc.csv" "$R/gpurun_out/${tag}_kernel_stats.csv" "$tag" "$@" > "$R/gpurun_out/${tag}_pmc_roofline.json" 2>> "$O/summary.txt"
 tail -5 "$O/summary.txt"

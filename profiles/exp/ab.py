@@ -54,10 +54,33 @@ def child(args):
     torch.cuda.synchronize()
     eng.kernel_times()
     eng.set_profiling(True)
+    # board power of the busiest GPU while the timed steps run (hwmon power1_input, microwatts)
+    import glob
+    import threading
+    import time
+    pfiles = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")
+    watts, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            best = 0.0
+            for f in pfiles:
+                try:
+                    best = max(best, float(open(f).read()) * 1e-6)
+                except (OSError, ValueError):
+                    pass
+            watts.append(best)
+            time.sleep(0.02)
+
+    th = threading.Thread(target=sample)
+    th.start()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    stop.set()
+    th.join()
     eng.set_profiling(False)
+    w = sorted(watts[len(watts) // 4:]) or [0.0]
     kt = eng.kernel_times()
     clk = eng.clock_sample() if hasattr(eng, "clock_sample") and hasattr(eng._lib, "tfhe_hip_get_clock_sample") else {}
     out = to.cpu().numpy().view(np.uint32)
@@ -69,14 +92,15 @@ def child(args):
         digest = hashlib.sha256(out.tobytes()).hexdigest()[:16]
     print(json.dumps({"br_ms": kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"]),
                       "ks_ms": kt["key_switch_ms"] / max(1, kt["key_switch_launches"]),
-                      "mhz": round(clk.get("shader_mhz", 0.0), 1), "digest": digest, "decrypt_ok": ok}))
+                      "mhz": round(clk.get("shader_mhz", 0.0), 1), "watts": round(w[len(w) // 2]), "digest": digest,
+                      "decrypt_ok": ok}))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("libs", nargs="*")
     ap.add_argument("--rounds", type=int, default=2)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--params", default="SECURITY_128_BIT")
     ap.add_argument("--gate", default="nand")
@@ -98,12 +122,13 @@ def main():
             d = json.loads(line[-1])
             res.setdefault(lib, []).append(d)
             print(f"round {r} {os.path.basename(lib):28s} br {d['br_ms']:8.2f} ms  ks {d['ks_ms']:6.2f} ms  "
-                  f"{d['mhz']:7.1f} MHz  digest {d['digest']}  decrypt_ok {d['decrypt_ok']}", flush=True)
+                  f"{d['mhz']:7.1f} MHz {d.get('watts', 0):5d} W  digest {d['digest']}  decrypt_ok {d['decrypt_ok']}", flush=True)
     print("\nsummary (min / median blind-rotate ms over rounds)")
     for lib, ds in res.items():
         v = sorted(d["br_ms"] for d in ds)
         print(f"  {os.path.basename(lib):28s} min {v[0]:8.2f}  med {v[len(v) // 2]:8.2f}  "
-              f"ks {min(d['ks_ms'] for d in ds):6.2f}  mhz {ds[-1]['mhz']}  digest {ds[-1]['digest']}")
+              f"ks {min(d['ks_ms'] for d in ds):6.2f}  mhz {ds[-1]['mhz']}  W {ds[-1].get('watts')}  Mcyc {v[0] * ds[-1]['mhz'] / 1e3:7.1f}  "
+              f"digest {ds[-1]['digest']}")
 
 
 if __name__ == "__main__":

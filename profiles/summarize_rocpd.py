@@ -26,7 +26,7 @@ def kernel_stats(db, out):
     }
     with open(out, "w", newline="") as f:
         w = csv.writer(f)
-        w.writerow(["kernel", "calls", "total_us", "avg_us", "pct", "vgpr", "agpr", "sgpr", "lds_bytes", "scratch",
+        w.writerow(["kernel", "calls", "total_us", "avg_us", "pct", "vgpr_rocpd_raw", "agpr_rocpd_raw", "sgpr", "lds_bytes", "scratch",
                     "grid_x", "workgroup_x"])
         for name, calls, tot, avg, pct in rows:
             w.writerow([name, calls, f"{tot:.0f}", f"{avg:.0f}", f"{pct:.3f}", *extra.get(name, [""] * 7)])

@@ -10,11 +10,11 @@ from . import _capi, bootstrap, circuit, client, distributed, engine, gates, key
 from .bootstrap import Bootstrap, HipBootstrap, LutBootstrap, default_bootstrap  # noqa: F401
 from .circuit import Circuit  # noqa: F401
 from .client import SecretKey  # noqa: F401
-from .engine import Engine  # noqa: F401
+from .engine import Engine, Pool  # noqa: F401
 from .gates import Gates  # noqa: F401
 from .key import CloudKey  # noqa: F401
 from .params import SECURITY_128_BIT, SecurityParams  # noqa: F401
 
-__all__ = ["Engine", "Gates", "CloudKey", "Bootstrap", "HipBootstrap", "LutBootstrap", "default_bootstrap",
+__all__ = ["Engine", "Pool", "Gates", "CloudKey", "Bootstrap", "HipBootstrap", "LutBootstrap", "default_bootstrap",
            "SecurityParams", "SECURITY_128_BIT", "gates", "key", "params", "bootstrap", "lut", "engine",
            "distributed", "circuit", "Circuit", "client", "SecretKey"]

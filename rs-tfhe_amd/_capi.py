@@ -57,6 +57,11 @@ SIGNATURES = {
     "tfhe_hip_name": (C.c_char_p, []),
     "tfhe_hip_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
     "tfhe_hip_gen_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, C.c_uint64]),
+    "tfhe_hip_gen_cloud_key_secure": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double]),
+    "tfhe_hip_gen_cloud_key_with_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, _P]),
+    "tfhe_hip_cloud_key_buffers": (C.c_int, [_CTX, C.POINTER(_P), C.POINTER(_SZ), C.POINTER(_P), C.POINTER(_SZ),
+                                             C.POINTER(_P), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
+    "tfhe_hip_adopt_cloud_key": (C.c_int, [_CTX, C.c_uint32]),
     "tfhe_hip_export_cloud_key": (C.c_int, [_CTX, _P, _P, C.POINTER(C.c_uint32), _P]),
     "tfhe_hip_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
@@ -84,6 +89,23 @@ SIGNATURES = {
     "tfhe_hip_get_kernel_times": (C.c_int, [_CTX, C.POINTER(KernelTimes)]),
     "tfhe_hip_get_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
+    # several GPUs behind one handle
+    "tfhe_hip_pool_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(_CTX)]),
+    "tfhe_hip_pool_destroy": (None, [_CTX]),
+    "tfhe_hip_pool_size": (C.c_int, [_CTX]),
+    "tfhe_hip_pool_ctx": (_CTX, [_CTX, C.c_int]),
+    "tfhe_hip_pool_last_error": (C.c_char_p, [_CTX]),
+    "tfhe_hip_pool_shard": (None, [_SZ, C.c_int, C.c_int, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "tfhe_hip_pool_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
+    "tfhe_hip_pool_gen_cloud_key_secure": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double]),
+    "tfhe_hip_pool_gen_cloud_key_with_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, _P]),
+    "tfhe_hip_pool_gen_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, C.c_uint64]),
+    "tfhe_hip_pool_export_cloud_key": (C.c_int, [_CTX, C.c_int, _P, _P, C.POINTER(C.c_uint32), _P]),
+    "tfhe_hip_pool_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
+    "tfhe_hip_pool_batch_gates_mixed": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_pool_batch_bootstrap": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ]),
+    "tfhe_hip_pool_batch_mux": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_pool_batch_blind_rotate": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
 }
 
 _lib = None

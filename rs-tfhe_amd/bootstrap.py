@@ -12,6 +12,8 @@ to be fed.
 from __future__ import annotations
 
 import abc
+import contextlib
+import threading
 
 import numpy as np
 
@@ -19,16 +21,54 @@ from .engine import COPY, Engine
 from .lut import Generator, LookupTable
 from .params import DEFAULT_SECURITY, SecurityParams
 
-_engines: dict = {}
+_engines: dict = {}  # (params, device) -> [Engine, ...]
+_engines_mu = threading.Lock()
+MAX_ENGINES_PER_SET = 4  # resident cloud keys per (parameter set, device): 172 MB each at SECURITY_128_BIT
 
 
 def engine_for(params: SecurityParams, device: int = 0) -> Engine:
-    """One Engine (C-ABI context) per (parameter set, device) in this process."""
-    key = (params, device)
-    eng = _engines.get(key)
-    if eng is None:
-        eng = _engines[key] = Engine(params, device)
-    return eng
+    """The first Engine (C-ABI context) of (parameter set, device) in this process."""
+    with _engines_mu:
+        pool = _engines.setdefault((params, device), [])
+        if not pool:
+            pool.append(Engine(params, device))
+        return pool[0]
+
+
+@contextlib.contextmanager
+def keyed_engine(cloud_key, device: int = 0):
+    """An Engine holding exactly `cloud_key`, locked for the duration of the `with` body.
+
+    The reference passes `&CloudKey` into every call (bootstrap/mod.rs:23-38 is `Send + Sync`); a context holds
+    one key at a time, so choosing the key and launching under it must be ONE critical section -- two threads
+    with two keys would otherwise compute under each other's key.  Up to MAX_ENGINES_PER_SET keys stay resident
+    per (parameter set, device), so alternating between a few keys does not re-upload them; beyond that the
+    least recently used context takes the new key."""
+    params = _params_of(cloud_key)
+    with _engines_mu:
+        pool = _engines.setdefault((params, device), [])
+        eng = next((e for e in pool if e._key is cloud_key), None)
+        if eng is None:
+            eng = next((e for e in pool if e._key is None), None)
+        if eng is None and len(pool) < MAX_ENGINES_PER_SET:
+            eng = Engine(params, device)
+            pool.append(eng)
+        if eng is None:
+            eng = min(pool, key=lambda e: e._last_use)
+        eng._last_use = next(_ticks)
+    with eng.lock:
+        eng.ensure_key(cloud_key)
+        yield eng
+
+
+def _tick_counter():
+    i = 0
+    while True:
+        i += 1
+        yield i
+
+
+_ticks = _tick_counter()
 
 
 def _params_of(cloud_key) -> SecurityParams:
@@ -55,19 +95,16 @@ class HipBootstrap(Bootstrap):
     def __init__(self, device: int = 0):
         self.device = device
 
-    def _engine(self, cloud_key) -> Engine:
-        eng = engine_for(_params_of(cloud_key), self.device)
-        eng.ensure_key(cloud_key)
-        return eng
-
     def bootstrap(self, ctxt, cloud_key):  # vanilla.rs:40-52
         ctxt = np.asarray(ctxt, dtype=np.uint32)
-        out = self._engine(cloud_key).batch_bootstrap(ctxt, None, True)
+        with keyed_engine(cloud_key, self.device) as eng:
+            out = eng.batch_bootstrap(ctxt, None, True)
         return out[0] if ctxt.ndim == 1 else out
 
     def bootstrap_without_key_switch(self, ctxt, cloud_key):  # vanilla.rs:54-63
         ctxt = np.asarray(ctxt, dtype=np.uint32)
-        out = self._engine(cloud_key).batch_bootstrap(ctxt, None, False)
+        with keyed_engine(cloud_key, self.device) as eng:
+            out = eng.batch_bootstrap(ctxt, None, False)
         return out[0] if ctxt.ndim == 1 else out
 
     def name(self) -> str:  # vanilla.rs:65-67 returns "vanilla"
@@ -83,7 +120,8 @@ class LutBootstrap(HipBootstrap):
 
     def bootstrap_lut(self, ct_in, lut: LookupTable, cloud_key):  # lut.rs:79-99
         ct_in = np.asarray(ct_in, dtype=np.uint32)
-        out = self._engine(cloud_key).batch_bootstrap(ct_in, lut.poly, True)
+        with keyed_engine(cloud_key, self.device) as eng:
+            out = eng.batch_bootstrap(ct_in, lut.poly, True)
         return out[0] if ct_in.ndim == 1 else out
 
     def bootstrap(self, ctxt, cloud_key):  # lut.rs:108-111: identity function, m = 2

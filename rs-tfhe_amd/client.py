@@ -11,10 +11,15 @@ the GPU except `cloud_key()`, which runs the key generation kernels.  Mirrors
   utils::f64_to_torus / gaussian_f64       src/utils.rs:9-38
   CloudKey::new(&secret_key)               src/key.rs:59-66
 
-The reference draws from an unseeded `thread_rng`; here every call takes a seed
-(or a numpy Generator) so runs are reproducible.
+The reference draws from `thread_rng` (an OS-seeded ChaCha CSPRNG).  Here `seed=None` -- the
+default everywhere -- draws from the operating system's CSPRNG (`os.urandom`); passing an integer
+seed or a numpy Generator selects numpy's PCG64 instead, which is reproducible and NOT
+cryptographic: tests and benchmarks only.  A guessable generator behind `SecretKey.new`,
+`encrypt_*` or `cloud_key` gives the secret key away.
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 
@@ -32,8 +37,38 @@ def torus_to_f64(t) -> np.ndarray:
     return np.asarray(t, dtype=np.uint32).astype(np.float64) / 4294967296.0
 
 
-def _rng(seed) -> np.random.Generator:
-    return seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
+class OsRng:
+    """The two draws this module needs, fed by os.urandom (getrandom(2)): the stand-in for the
+    reference's OS-seeded thread_rng."""
+
+    def integers(self, low, high, size, dtype=np.uint64):
+        span = int(high) - int(low)
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        count = int(np.prod(shape))
+        if span == 2:
+            raw = np.frombuffer(os.urandom((count + 7) // 8), np.uint8)
+            vals = np.unpackbits(raw)[:count].astype(np.uint64)
+        elif span == 1 << 32:
+            vals = np.frombuffer(os.urandom(4 * count), np.uint32).astype(np.uint64)
+        else:
+            raise ValueError("OsRng.integers serves bits and 32-bit words")
+        return (vals + np.uint64(int(low))).astype(dtype).reshape(shape)
+
+    def normal(self, mu, sigma, size):
+        """Box-Muller over 53-bit uniforms (as the GPU key generator does, keygen.hpp gauss2)."""
+        count = int(size)
+        u = np.frombuffer(os.urandom(16 * ((count + 1) // 2)), np.uint64).reshape(-1, 2) >> np.uint64(11)
+        u1 = (u[:, 0].astype(np.float64) + 1.0) * (1.0 / 9007199254740992.0)  # (0, 1]
+        u2 = u[:, 1].astype(np.float64) * (1.0 / 9007199254740992.0)          # [0, 1)
+        r = np.sqrt(-2.0 * np.log(u1)) * sigma
+        return (mu + np.concatenate([r * np.cos(2 * np.pi * u2), r * np.sin(2 * np.pi * u2)]))[:count]
+
+
+def _rng(seed):
+    """None -> OsRng (cryptographic); int / numpy Generator -> PCG64 (reproducible, tests only)."""
+    if seed is None:
+        return OsRng()
+    return seed if isinstance(seed, (np.random.Generator, OsRng)) else np.random.default_rng(seed)
 
 
 class SecretKey:
@@ -99,13 +134,15 @@ class SecretKey:
         return (torus_to_f64(self.phase(cts)) / scale + 0.5).astype(np.int64) % m
 
     # ---- evaluation key ----------------------------------------------------------------------
-    def cloud_key(self, seed: int = 0, device: int = 0):
-        """CloudKey::new(&secret_key) (key.rs:59-66): generated on the GPU (`tfhe_hip_gen_cloud_key`),
-        left loaded in the shared engine for `device`, and returned in the reference layouts."""
+    def cloud_key(self, seed=None, device: int = 0):
+        """CloudKey::new(&secret_key) (key.rs:59-66): generated on the GPU, left loaded in the shared engine for
+        `device`, and returned in the reference layouts.  seed=None: the generator key comes from the OS
+        (`tfhe_hip_gen_cloud_key_secure`); an integer seed gives a reproducible, guessable key (tests only)."""
         from .bootstrap import engine_for
 
         eng = engine_for(self.params, device)
-        eng.gen_cloud_key(self.key_lv0, self.key_lv1, seed)
-        ck = eng.export_cloud_key()
-        eng._key = ck  # the engine already holds exactly this key: no re-upload on first use
+        with eng.lock:
+            eng.gen_cloud_key(self.key_lv0, self.key_lv1, seed)
+            ck = eng.export_cloud_key()
+            eng._key = ck  # the engine already holds exactly this key: no re-upload on first use
         return ck

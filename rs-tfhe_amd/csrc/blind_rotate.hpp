@@ -71,7 +71,7 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 #define TFHE_PREFETCH_A 8
 #endif
 #ifndef TFHE_PREFETCH_B
-#define TFHE_PREFETCH_B 8
+#define TFHE_PREFETCH_B 4
 #endif
 // 1 = the two inverse transforms of a CMUX step are interleaved through the one tile (fft_inverse2)
 #ifndef TFHE_INV_PAIR
@@ -86,6 +86,22 @@ __device__ __forceinline__ int32_t sbfe(uint32_t src, int shift, int width) {
   int32_t d;
   asm("v_bfe_i32 %0, %1, %2, %3" : "=v"(d) : "v"(src), "s"(shift), "v"(width));
   return d;
+}
+
+// Waves per workgroup of the batch kernel (each wave still owns one ciphertext and its own LDS regions) and
+// how tightly a workgroup's waves are held together: 0 = free-running, 1 = one barrier per CMUX step,
+// 2 = per polynomial half, 3 = per digit row.  Waves that walk the key together fetch each 1-KiB key slice
+// within a few hundred cycles of each other, so all but the first are served by the CU's vector L1 instead
+// of the L2 -- the L2 -> L1 key stream (68.8 MB per ciphertext) is what holds the shader clock down.
+#ifndef TFHE_WG_WAVES
+#define TFHE_WG_WAVES 4
+#endif
+#ifndef TFHE_WG_SYNC
+#define TFHE_WG_SYNC 1
+#endif
+template <int LEVEL>
+__device__ __forceinline__ void wg_sync() {
+  if (TFHE_WG_WAVES > 1 && TFHE_WG_SYNC >= LEVEL) __builtin_amdgcn_s_barrier();
 }
 
 // f (+)= x * v, complex, as four fused multiply-adds (fma_in_fd_1024, trgsw.rs:118-142; the 0.5 of the
@@ -112,6 +128,7 @@ __device__ __forceinline__ void external_product_row(int r, int shift, const uin
                                                      int lane, int bgbit, double (&fa_re)[8], double (&fa_im)[8],
                                                      double (&fb_re)[8], double (&fb_im)[8]) {
   const uint32_t lane_off = (uint32_t)lane * 16u;
+  wg_sync<3>();
   // key row r: 2 x 8 coalesced 16-byte loads per lane off one buffer descriptor (lane
   // offset in a VGPR, row offset in an SGPR: no per-lane address arithmetic), issued
   // ahead of the FFT they are consumed after, so their latency hides under it.
@@ -160,6 +177,7 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
     w_lo[m] = t_lo[m] ^ signmask;
     w_hi[m] = t_hi[m] ^ signmask;
   }
+  if (TFHE_WG_SYNC == 2) wg_sync<2>();
   external_product_row<L, INIT0>(half_sel * L, 32 - bgbit, w_lo, w_hi, bsk_rsrc, bsk_i_off, tw, tile, lane, bgbit,
                                  fa_re, fa_im, fb_re, fb_im);
   // The remaining rows stay a LOOP: with the body duplicated (or, at L = 2, the one-trip loop flattened)
@@ -260,6 +278,7 @@ struct BlindRotateArgs {
   uint32_t *out_trlwe;  // [count][2][N]
   uint32_t *out_lv1;    // [count][N+1]  sample_extract_index(.,0)
   uint32_t *out_ext2;   // [count][n+1]  sample_extract_index_2(.,0)
+  size_t count;         // ciphertexts of this launch (the last workgroup may be partly filled)
   // diagnostics (may be null)
   unsigned long long *clk;  // [2]: += shader cycles (s_memtime) and += constant-rate ticks (s_memrealtime) per workgroup
   uint32_t *err_flag;       // |= 1 when a gate code outside tfhe_hip_gate is seen (the ciphertext is then treated as COPY)
@@ -274,8 +293,12 @@ __device__ constexpr uint32_t kGateCc[11] = {0x20000000u, 0x20000000u, 0xE000000
 
 // LDS per workgroup: FFT tile | accumulator (a then b, natural order) | T2 table | rotation amounts
 constexpr int kAccBytes = 2 * kN * 4;
-__host__ __device__ __forceinline__ size_t blind_rotate_lds_bytes(int n) {
+constexpr int kBrWaves = TFHE_WG_WAVES;  // waves (= ciphertexts) per workgroup of k_blind_rotate
+__host__ __device__ __forceinline__ size_t blind_rotate_wave_lds_bytes(int n) {
   return ((size_t)kTileBytes + kAccBytes + kT2Bytes + (size_t)n * 2 + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t blind_rotate_lds_bytes(int n) {
+  return kBrWaves * blind_rotate_wave_lds_bytes(n);
 }
 constexpr int kStageLdsBytes = kTileBytes + kT2Bytes;  // stage kernels: tile | T2 table
 
@@ -284,15 +307,21 @@ constexpr int kStageLdsBytes = kTileBytes + kT2Bytes;  // stage kernels: tile | 
 // never materialises), and the 32 VGPRs an in-register accumulator would pin across
 // the eight FFTs are free, which is what lets two waves share a SIMD (<= 256 VGPRs).
 template <int L, bool FAST>
-__global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateArgs A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+  const int n = A.n;
+  const int lane = threadIdx.x & 63;
+  const int wave = kBrWaves > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+  unsigned char *smem = smem_wg + (size_t)wave * blind_rotate_wave_lds_bytes(n);
   double2 *tile = reinterpret_cast<double2 *>(smem);
   uint32_t *acc = reinterpret_cast<uint32_t *>(smem + kTileBytes);
   double2 *t2tab = reinterpret_cast<double2 *>(smem + kTileBytes + kAccBytes);
   uint16_t *s_abar = reinterpret_cast<uint16_t *>(smem + kTileBytes + kAccBytes + kT2Bytes);
-  const int lane = threadIdx.x;
-  const size_t ct = blockIdx.x;
-  const int n = A.n;
+  // a partly filled last workgroup: the spare waves redo the last ciphertext (they take part in the
+  // barriers) and store nothing
+  size_t ct = (size_t)blockIdx.x * kBrWaves + wave;
+  const bool live = ct < A.count;
+  if (!live) ct = A.count - 1;
   const unsigned long long clk0 = A.clk ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rtc0 = A.clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
@@ -345,6 +374,7 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
   for (int i = 0; i < L; ++i) signmask |= 1u << (32 - i * A.bgbit - 1);
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
+    wg_sync<1>();
     const int k = s_abar[i];
     double fa_re[8], fa_im[8], fb_re[8], fb_im[8];  // written by the first row of the a half
 #if TFHE_FWD_PAIR
@@ -466,6 +496,7 @@ __global__ __launch_bounds__(64, 2) void k_blind_rotate(BlindRotateArgs A) {
   }
 
   // ---- epilogue (acc is final; any lane may read any coefficient) -------------
+  if (!live) return;
   if (A.out_trlwe) {
     uint32_t *o = A.out_trlwe + ct * (size_t)(2 * kN);
 #pragma unroll

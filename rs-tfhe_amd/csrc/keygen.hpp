@@ -7,43 +7,53 @@
 // forward FFTs).  The keys are written straight into the engine layouts, so the 172 MB upload
 // and the two conversion kernels disappear.
 //
-// Randomness: the reference draws from an unseeded thread_rng (tlwe.rs:38, trlwe.rs:36-41); here a
-// counter-based Philox4x32-10 stream keyed by (seed, row) gives every word a fixed position, so a
-// seed reproduces a key bit-for-bit on any launch geometry.  Distributions are the reference's:
-// uniform u32 mask, N(0, alpha) noise added on the torus via f64_to_torus (utils.rs:9-38).
+// Randomness: the reference draws from an OS-seeded ChaCha thread_rng (tlwe.rs:38, trlwe.rs:36-41).  Here every
+// mask word and every Gaussian sample is a fixed position of a ChaCha20 keystream (RFC 8439 block function,
+// 20 rounds) under a 256-bit key: block (counter, nonce = {row, stream, domain}).  The published key rows are
+// (mask, <mask, s> + noise); whoever can regenerate the noise reads the secret key off them, so the 256-bit key
+// must come from the OS (tfhe_hip_gen_cloud_key_secure) or from the caller's own CSPRNG (..._with_key).  The
+// 64-bit-seed entry point expands the seed into a key and exists for reproducible tests and benchmarks only.
+// Distributions are the reference's: uniform u32 mask, N(0, alpha) noise added on the torus (utils.rs:9-38).
 #pragma once
 #include "blind_rotate.hpp"
 #include "key_switch.hpp"
 
 namespace tfhe {
 
-// ---- Philox4x32-10 ------------------------------------------------------------------
-struct Philox {
-  uint32_t k0, k1;
-  __device__ __forceinline__ void round(uint32_t (&c)[4], uint32_t a, uint32_t b) const {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ a;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ b;
-    c[1] = (uint32_t)p1;
-    c[3] = (uint32_t)p0;
-    c[0] = n0;
-    c[2] = n2;
-  }
-  // 4 words for counter (c0, c1, c2, c3)
-  __device__ __forceinline__ void gen(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t (&out)[4]) const {
-    uint32_t c[4] = {c0, c1, c2, c3};
-    uint32_t a = k0, b = k1;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-      round(c, a, b);
-      a += 0x9E3779B9u;
-      b += 0xBB67AE85u;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out[i] = c[i];
-  }
+// ---- ChaCha20 block function (RFC 8439 section 2.3) -------------------------------------
+struct ChaChaKey {
+  uint32_t k[8];
 };
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+#define TFHE_QR(a, b, c, d) \
+  a += b; d ^= a; d = rotl32(d, 16); \
+  c += d; b ^= c; b = rotl32(b, 12); \
+  a += b; d ^= a; d = rotl32(d, 8);  \
+  c += d; b ^= c; b = rotl32(b, 7);
+// 16 keystream words of block `counter` under nonce (n0, n1, n2)
+__device__ __forceinline__ void chacha20_block(const ChaChaKey &key, uint32_t counter, uint32_t n0, uint32_t n1, uint32_t n2,
+                                               uint32_t (&out)[16]) {
+  const uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key.k[0], key.k[1], key.k[2], key.k[3],
+                           key.k[4],    key.k[5],    key.k[6],    key.k[7],    counter,  n0,       n1,       n2};
+  uint32_t x0 = in[0], x1 = in[1], x2 = in[2], x3 = in[3], x4 = in[4], x5 = in[5], x6 = in[6], x7 = in[7], x8 = in[8],
+           x9 = in[9], x10 = in[10], x11 = in[11], x12 = in[12], x13 = in[13], x14 = in[14], x15 = in[15];
+#pragma unroll 1
+  for (int r = 0; r < 10; ++r) {  // 10 double rounds
+    TFHE_QR(x0, x4, x8, x12)
+    TFHE_QR(x1, x5, x9, x13)
+    TFHE_QR(x2, x6, x10, x14)
+    TFHE_QR(x3, x7, x11, x15)
+    TFHE_QR(x0, x5, x10, x15)
+    TFHE_QR(x1, x6, x11, x12)
+    TFHE_QR(x2, x7, x8, x13)
+    TFHE_QR(x3, x4, x9, x14)
+  }
+  out[0] = x0 + in[0];    out[1] = x1 + in[1];    out[2] = x2 + in[2];    out[3] = x3 + in[3];
+  out[4] = x4 + in[4];    out[5] = x5 + in[5];    out[6] = x6 + in[6];    out[7] = x7 + in[7];
+  out[8] = x8 + in[8];    out[9] = x9 + in[9];    out[10] = x10 + in[10]; out[11] = x11 + in[11];
+  out[12] = x12 + in[12]; out[13] = x13 + in[13]; out[14] = x14 + in[14]; out[15] = x15 + in[15];
+}
+#undef TFHE_QR
 
 // src/utils.rs:9-12
 __device__ __forceinline__ uint32_t dev_f64_to_torus(double d) {
@@ -52,7 +62,7 @@ __device__ __forceinline__ uint32_t dev_f64_to_torus(double d) {
 }
 
 // two N(0, sigma) samples from four uniform words (Box-Muller)
-__device__ __forceinline__ void gauss2(const uint32_t (&w)[4], double sigma, double &g0, double &g1) {
+__device__ __forceinline__ void gauss2(const uint32_t *w, double sigma, double &g0, double &g1) {
   const double u1 = ((double)(((uint64_t)w[0] << 21) ^ (w[1] >> 11)) + 1.0) * (1.0 / 9007199254740992.0);  // (0,1]
   const double u2 = (double)(((uint64_t)w[2] << 21) ^ (w[3] >> 11)) * (1.0 / 9007199254740992.0);          // [0,1)
   const double rad = sqrt(-2.0 * log(u1)) * sigma;
@@ -70,7 +80,7 @@ __device__ __forceinline__ uint32_t gaussian_torus(double mu, double g) { return
 // (tlwe.rs:37-53): a uniform, b = <a, s0> + gaussian_f64(p).
 __global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ key_lv0, const uint32_t *__restrict__ key_lv1,
                                                   uint32_t *__restrict__ ksk_eng, int n, int basebit, int t,
-                                                  double alpha, uint32_t seed_lo, uint32_t seed_hi) {
+                                                  double alpha, ChaChaKey key) {
   __shared__ uint32_t s_part[4];
   const uint32_t row = blockIdx.x;  // base*t*i + base*j + k
   const int base = 1 << basebit;
@@ -82,14 +92,13 @@ __global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ ke
     for (int x = tid; x < rw; x += 256) dst[x] = 0u;
     return;
   }
-  const Philox ph{seed_lo, seed_hi ^ 0x4B53u};
   uint32_t inner = 0;
-  for (int x4 = tid; x4 * 4 < n; x4 += 256) {
-    uint32_t w[4];
-    ph.gen((uint32_t)x4, row, 0u, 0u, w);
+  for (int x16 = tid; x16 * 16 < n; x16 += 256) {  // one keystream block = 16 mask words
+    uint32_t w[16];
+    chacha20_block(key, (uint32_t)x16, row, 0u, 0x4B534Bu /* "KSK" */, w);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int x = x4 * 4 + c;
+    for (int c = 0; c < 16; ++c) {
+      const int x = x16 * 16 + c;
       if (x < n) {
         dst[x] = w[c];
         inner += key_lv0[x] * w[c];
@@ -102,8 +111,8 @@ __global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ ke
   __syncthreads();
   if (tid == 0) {
     const uint32_t total = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    uint32_t w[4];
-    ph.gen(0xFFFFFFFFu, row, 1u, 0u, w);
+    uint32_t w[16];
+    chacha20_block(key, 0u, row, 1u, 0x4B534Bu, w);
     double g0, g1;
     gauss2(w, alpha, g0, g1);
     const double p = (double)((uint32_t)k * key_lv1[i]) / (double)(1u << ((j + 1) * basebit));  // key.rs:113-114
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(64) void k_key_spectrum(const uint32_t *__restrict_
 template <int L>
 __global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key_lv0, const double2 *__restrict__ s1_spec,
                                                  const double2 *__restrict__ twt, double2 *__restrict__ bsk_eng,
-                                                 int bgbit, double alpha, uint32_t seed_lo, uint32_t seed_hi) {
+                                                 int bgbit, double alpha, ChaChaKey key) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
   const int lane = threadIdx.x;
@@ -147,28 +156,30 @@ __global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key
   const int r = row % (2 * L), i = row / (2 * L);
   Twiddles tw;
   tw.load(twt, reinterpret_cast<double2 *>(smem + kTileBytes), lane);
-  const Philox ph{seed_lo, seed_hi ^ 0x4253u};
 
   // a: uniform; e: gaussian.  Lane l owns coefficients l+64m (lo) and l+64m+512 (hi), m < 8:
-  // 16 words of each per lane = 4 Philox blocks for a, 8 for the Gaussian pairs.
+  // 16 mask words per lane = one keystream block, 8 Gaussian pairs = 32 words = two more.
   uint32_t a_lo[8], a_hi[8], b_lo[8], b_hi[8];
+  {
+    uint32_t w[16];
+    chacha20_block(key, (uint32_t)lane, row, 2u, 0x42534Bu /* "BSK" */, w);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    uint32_t w[4];
-    ph.gen((uint32_t)(lane * 4 + q), row, 2u, 0u, w);
-    a_lo[2 * q] = w[0];
-    a_lo[2 * q + 1] = w[1];
-    a_hi[2 * q] = w[2];
-    a_hi[2 * q + 1] = w[3];
+    for (int q = 0; q < 8; ++q) {
+      a_lo[q] = w[q];
+      a_hi[q] = w[8 + q];
+    }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    uint32_t w[4];
-    ph.gen((uint32_t)(lane * 8 + q), row, 3u, 0u, w);
-    double g0, g1;
-    gauss2(w, alpha, g0, g1);
-    b_lo[q] = gaussian_torus(0.0, g0);
-    b_hi[q] = gaussian_torus(0.0, g1);
+  for (int h = 0; h < 2; ++h) {
+    uint32_t w[16];
+    chacha20_block(key, (uint32_t)(lane * 2 + h), row, 3u, 0x42534Bu, w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      double g0, g1;
+      gauss2(w + 4 * q, alpha, g0, g1);
+      b_lo[4 * h + q] = gaussian_torus(0.0, g0);
+      b_hi[4 * h + q] = gaussian_torus(0.0, g1);
+    }
   }
   // poly_res = a (*) s1 (klemsa.rs:152-174): A*S/512 through the inverse
   double re[8], im[8];

@@ -1,0 +1,232 @@
+// pool.hpp -- several GPUs behind ONE handle of the C ABI (included by tfhe_hip.hip; needs tfhe_hip_ctx).
+//
+// The reference's batch entry points are `par_iter().map().collect()` over the ciphertexts of a slice
+// (src/parallel/rayon_impl.rs:40-47, called from src/gates.rs:357-383): order-preserving, embarrassingly
+// parallel, one shared read-only &CloudKey.  The pool is that map over devices: one context per device, the
+// cloud key generated / uploaded ONCE and replicated device-to-device in the engine layouts (no second
+// conversion, no host round trip), a contiguous order-preserving split of the batch, one host thread per
+// shard (each thread makes its shard's device current; the HIP current device is per thread), results
+// written in place into the caller's output slice.  No collective and no exchange on the data path.
+#pragma once
+#include <thread>
+
+struct tfhe_hip_pool {
+  std::vector<tfhe_hip_ctx *> ctxs;
+  std::mutex mu;  // one batch at a time per pool (the contexts' host staging buffers are per context)
+  std::string err = "";
+};
+
+namespace {
+
+// [lo, hi) of shard r of `world` over `count` items: contiguous, order-preserving, sizes differ by at most 1
+inline void pool_shard(size_t count, int r, int world, size_t &lo, size_t &hi) {
+  const size_t base = count / (size_t)world, rem = count % (size_t)world;
+  lo = (size_t)r * base + ((size_t)r < rem ? (size_t)r : rem);
+  hi = lo + base + ((size_t)r < rem ? 1 : 0);
+}
+
+int pool_fail(tfhe_hip_pool *p, int code, const std::string &msg) {
+  p->err = msg;
+  return code;
+}
+
+// dst takes src's key (engine layouts), device to device.  Both contexts idle on entry.
+int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
+  std::lock_guard<std::mutex> lk(dst->mu);
+  DeviceGuard dg(dst->device);
+  if (dg.err != hipSuccess) return fail(dst, TFHE_HIP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(dg.err));
+  if (dst->scratch_owned) HIPCHK(dst, hipStreamSynchronize(dst->scratch_owner));
+  HIPCHK(dst, hipStreamSynchronize(dst->stream));
+  dst->scratch_owned = false;
+  const tfhe_hip_params &P = dst->P;
+  const size_t bsk_bytes = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
+  const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
+  dst->key_loaded = false;
+  if (!dst->d_bsk) HIPCHK(dst, hipMalloc((void **)&dst->d_bsk, bsk_bytes));
+  if (!dst->d_ksk) HIPCHK(dst, hipMalloc((void **)&dst->d_ksk, ksk_bytes + 4096));
+  if (!dst->d_testvec) HIPCHK(dst, hipMalloc((void **)&dst->d_testvec, 2 * kN * 4));
+  HIPCHK(dst, hipMemcpyPeer(dst->d_bsk, dst->device, src->d_bsk, src->device, bsk_bytes));
+  HIPCHK(dst, hipMemcpyPeer(dst->d_ksk, dst->device, src->d_ksk, src->device, ksk_bytes));
+  HIPCHK(dst, hipMemcpyPeer(dst->d_testvec, dst->device, src->d_testvec, src->device, 2 * kN * 4));
+  HIPCHK(dst, hipDeviceSynchronize());
+  dst->offset = src->offset;
+  dst->key_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+int replicate_key(tfhe_hip_pool *p) {
+  for (size_t i = 1; i < p->ctxs.size(); ++i) {
+    const int rc = clone_key(p->ctxs[i], p->ctxs[0]);
+    if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(p->ctxs[i]->device) + ": " + p->ctxs[i]->err);
+  }
+  return TFHE_HIP_OK;
+}
+
+// run(ctx, lo, hi) on every non-empty shard, shard 0 on the calling thread; first failure wins
+template <class F>
+int pool_map(tfhe_hip_pool *p, size_t count, F &&run) {
+  const int world = (int)p->ctxs.size();
+  std::vector<int> rc((size_t)world, TFHE_HIP_OK);
+  std::vector<std::thread> th;
+  for (int r = 1; r < world; ++r) {
+    size_t lo, hi;
+    pool_shard(count, r, world, lo, hi);
+    if (hi > lo) th.emplace_back([&, r, lo, hi] { rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi); });
+  }
+  {
+    size_t lo, hi;
+    pool_shard(count, 0, world, lo, hi);
+    if (hi > lo) rc[0] = run(p->ctxs[0], lo, hi);
+  }
+  for (auto &t : th) t.join();
+  for (int r = 0; r < world; ++r)
+    if (rc[(size_t)r] != TFHE_HIP_OK)
+      return pool_fail(p, rc[(size_t)r], "device " + std::to_string(p->ctxs[(size_t)r]->device) + ": " + p->ctxs[(size_t)r]->err);
+  return TFHE_HIP_OK;
+}
+
+}  // namespace
+
+int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int ndev, tfhe_hip_pool **out) {
+  if (!out) return TFHE_HIP_EINVAL;
+  *out = nullptr;
+  if (!params || !devices || ndev <= 0 || ndev > 64) {
+    g_create_error = "pool: need 1..64 devices";
+    return TFHE_HIP_EINVAL;
+  }
+  tfhe_hip_pool *p = new tfhe_hip_pool();
+  for (int i = 0; i < ndev; ++i) {
+    tfhe_hip_ctx *c = nullptr;
+    const int rc = tfhe_hip_ctx_create(params, devices[i], &c);
+    if (rc != TFHE_HIP_OK) {  // g_create_error holds the text
+      for (auto *x : p->ctxs) tfhe_hip_ctx_destroy(x);
+      delete p;
+      return rc;
+    }
+    p->ctxs.push_back(c);
+  }
+  *out = p;
+  return TFHE_HIP_OK;
+}
+
+void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
+  if (!p) return;
+  for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);
+  delete p;
+}
+
+int tfhe_hip_pool_size(const tfhe_hip_pool *p) { return p ? (int)p->ctxs.size() : 0; }
+
+tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
+  return (p && i >= 0 && (size_t)i < p->ctxs.size()) ? p->ctxs[(size_t)i] : nullptr;
+}
+
+const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_t *hi) {
+  size_t a = 0, b = 0;
+  if (nshards > 0 && shard >= 0 && shard < nshards) pool_shard(count, shard, nshards, a, b);
+  if (lo) *lo = a;
+  if (hi) *hi = b;
+}
+
+#define POOL_ENTER(p)               \
+  if (!(p)) return TFHE_HIP_EINVAL; \
+  std::lock_guard<std::mutex> plk_((p)->mu)
+#define POOL_FIRST(p, call)                                                                                        \
+  do {                                                                                                             \
+    const int rc_ = (call);                                                                                        \
+    if (rc_ != TFHE_HIP_OK) return pool_fail(p, rc_, "device " + std::to_string((p)->ctxs[0]->device) + ": " + (p)->ctxs[0]->err); \
+  } while (0)
+
+int tfhe_hip_pool_load_cloud_key(tfhe_hip_pool *p, const double *bsk, const uint32_t *ksk, uint32_t decomp_offset,
+                                 const uint32_t *testvec) {
+  POOL_ENTER(p);
+  POOL_FIRST(p, tfhe_hip_load_cloud_key(p->ctxs[0], bsk, ksk, decomp_offset, testvec));
+  return replicate_key(p);
+}
+
+int tfhe_hip_pool_gen_cloud_key_secure(tfhe_hip_pool *p, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                       double alpha_ksk, double alpha_bsk) {
+  POOL_ENTER(p);
+  POOL_FIRST(p, tfhe_hip_gen_cloud_key_secure(p->ctxs[0], key_lv0, key_lv1, alpha_ksk, alpha_bsk));
+  return replicate_key(p);
+}
+
+int tfhe_hip_pool_gen_cloud_key_with_key(tfhe_hip_pool *p, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                         double alpha_ksk, double alpha_bsk, const uint8_t rng_key[32]) {
+  POOL_ENTER(p);
+  POOL_FIRST(p, tfhe_hip_gen_cloud_key_with_key(p->ctxs[0], key_lv0, key_lv1, alpha_ksk, alpha_bsk, rng_key));
+  return replicate_key(p);
+}
+
+int tfhe_hip_pool_gen_cloud_key(tfhe_hip_pool *p, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
+                                double alpha_bsk, uint64_t seed) {
+  POOL_ENTER(p);
+  POOL_FIRST(p, tfhe_hip_gen_cloud_key(p->ctxs[0], key_lv0, key_lv1, alpha_ksk, alpha_bsk, seed));
+  return replicate_key(p);
+}
+
+int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *p, int member, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
+                                   uint32_t *testvec) {
+  POOL_ENTER(p);
+  if (member < 0 || (size_t)member >= p->ctxs.size()) return pool_fail(p, TFHE_HIP_EINVAL, "no such pool member");
+  tfhe_hip_ctx *c = p->ctxs[(size_t)member];
+  const int rc = tfhe_hip_export_cloud_key(c, bsk, ksk, decomp_offset, testvec);
+  if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + c->err);
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_pool_batch_gate(tfhe_hip_pool *p, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
+                             size_t count) {
+  POOL_ENTER(p);
+  if (count && (!a || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_gate(c, gate, a + lo * w, b ? b + lo * w : nullptr, out + lo * w, hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *p, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                    uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_gates_mixed(c, gates + lo, a + lo * w, b + lo * w, out + lo * w, hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *p, const uint32_t *in, const uint32_t *testvec, int per_ct,
+                                  int keyswitch, uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!in || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  const size_t tvs = (testvec && per_ct) ? (size_t)2 * kN : 0;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_bootstrap(c, in + lo * w, testvec ? testvec + lo * tvs : nullptr, per_ct, keyswitch, out + lo * w,
+                                    hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_mux(tfhe_hip_pool *p, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c3,
+                            uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!a || !b || !c3 || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_mux(c, naive, a + lo * w, b + lo * w, c3 + lo * w, out + lo * w, hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_blind_rotate(tfhe_hip_pool *p, const uint32_t *in, const uint32_t *testvec, uint32_t *out_trlwe,
+                                     size_t count) {
+  POOL_ENTER(p);
+  if (count && (!in || !out_trlwe)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_blind_rotate(c, in + lo * w, testvec, out_trlwe + lo * (size_t)2 * kN, hi - lo);
+  });
+}
+#undef POOL_ENTER
+#undef POOL_FIRST

@@ -17,6 +17,9 @@
 #include <vector>
 
 #include "../../include/tfhe_hip.h"
+#include <errno.h>
+#include <sys/random.h>
+
 #include "blind_rotate.hpp"
 #include "key_switch.hpp"
 #include "keygen.hpp"
@@ -218,6 +221,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.out_trlwe = out_trlwe;
   A.out_lv1 = out_lv1;
   A.out_ext2 = out_ext2;
+  A.count = count;
   A.clk = ctx->profiling ? ctx->d_diag : nullptr;
   A.err_flag = reinterpret_cast<uint32_t *>(ctx->d_diag + 2);
   // sample_extract_index_2 reads a[n - i] of an N-coefficient polynomial (trlwe.rs:122-136): the reference
@@ -244,7 +248,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     ctx->bootstraps += count;
     return TFHE_HIP_OK;
   }
-  dim3 block(64);
+  dim3 block(64 * kBrWaves);
   size_t lds = br_lds_bytes(ctx);
   // Launch in rounds of exactly the resident set: every workgroup of a round starts
   // step 0 together and streams the bootstrapping key in near lock-step, so each key
@@ -256,10 +260,12 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (ctx->br_chunk < 0) {
     int per_cu = 0;
     hipError_t e = hipErrorUnknown;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64, lds);
-    if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * kBrWaves, lds);
+    if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * kBrWaves;
   }
   if (chunk == 0 || chunk > count) chunk = count;
+  if (lds > 64 * 1024)
+    HIPCHK(ctx, hipFuncSetAttribute((const void *)br_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (size_t done = 0; done < count; done += chunk) {
     const size_t m = (count - done < chunk) ? count - done : chunk;
     BlindRotateArgs S = A;
@@ -270,7 +276,8 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     if (A.out_trlwe) S.out_trlwe = A.out_trlwe + done * (size_t)(2 * kN);
     if (A.out_lv1) S.out_lv1 = A.out_lv1 + done * (size_t)(kN + 1);
     if (A.out_ext2) S.out_ext2 = A.out_ext2 + done * (size_t)(ctx->P.n + 1);
-    dim3 grid((unsigned)m);
+    S.count = m;
+    dim3 grid((unsigned)((m + kBrWaves - 1) / kBrWaves));
     CHK(record_begin(ctx, s, ctx->ev_br));
     hipLaunchKernelGGL(br_kernel(ctx), grid, block, lds, s, S);
     HIPCHK(ctx, hipGetLastError());
@@ -584,10 +591,10 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   return TFHE_HIP_OK;
 }
 
-int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
-                           double alpha_bsk, uint64_t seed) {
-  if (!ctx) return TFHE_HIP_EINVAL;
-  ENTER(ctx);
+namespace {
+// ctx->mu held, ctx's device current
+int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
+                         double alpha_bsk, const ChaChaKey &rk) {
   if (!key_lv0 || !key_lv1) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
   if (!(alpha_ksk >= 0.0) || !(alpha_bsk >= 0.0)) return fail(ctx, TFHE_HIP_EINVAL, "negative noise parameter");
   // Work queued earlier on the caller's streams (*_dev entry points) may still be reading the key this
@@ -608,18 +615,17 @@ int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uin
   CHK(ensure(ctx, ctx->h_c, (size_t)kN2 * sizeof(double2)));
   const uint32_t *d_k0 = (const uint32_t *)ctx->h_a.p, *d_k1 = (const uint32_t *)ctx->h_b.p;
   double2 *d_spec = (double2 *)ctx->h_c.p;
-  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
   hipLaunchKernelGGL(k_key_spectrum, dim3(1), dim3(64), kStageLdsBytes, ctx->stream, d_k1, ctx->d_tw, d_spec);
   HIPCHK(ctx, hipGetLastError());
   const dim3 bgrid((unsigned)(P.n * 2 * P.l));
   switch (P.l) {
-    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
-    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
-    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, slo, shi); break;
+    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
+    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
+    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
   }
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_gen_ksk, dim3((unsigned)((size_t)kN * P.t * base)), dim3(256), 0, ctx->stream, d_k0, d_k1,
-                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, slo, shi);
+                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, rk);
   HIPCHK(ctx, hipGetLastError());
   // decomposition offset (key.rs:78-89) and test vector (key.rs:91-100)
   uint32_t off = 0;
@@ -627,11 +633,73 @@ int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uin
   std::vector<uint32_t> tv(2 * kN, 0u);
   for (int i = 0; i < kN; ++i) tv[kN + i] = 0x20000000u;  // f64_to_torus(0.125)
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, tv.data(), 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
+  // the secret keys and the spectrum of the ring key do not outlive the call on the device
+  HIPCHK(ctx, hipMemsetAsync(ctx->h_a.p, 0, (size_t)P.n * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->h_b.p, 0, (size_t)kN * 4, ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->h_c.p, 0, (size_t)kN2 * sizeof(double2), ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->offset = off;
   ctx->key_loaded = true;
   return TFHE_HIP_OK;
 }
+
+// 64-bit seed -> 256-bit generator key (SplitMix64): reproducible, and only as strong as the seed
+ChaChaKey key_from_seed(uint64_t seed) {
+  ChaChaKey k;
+  uint64_t x = seed;
+  for (int i = 0; i < 4; ++i) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    k.k[2 * i] = (uint32_t)z;
+    k.k[2 * i + 1] = (uint32_t)(z >> 32);
+  }
+  return k;
+}
+}  // namespace
+
+int tfhe_hip_gen_cloud_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1, double alpha_ksk,
+                           double alpha_bsk, uint64_t seed) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  return gen_cloud_key_locked(ctx, key_lv0, key_lv1, alpha_ksk, alpha_bsk, key_from_seed(seed));
+}
+
+int tfhe_hip_gen_cloud_key_with_key(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                    double alpha_ksk, double alpha_bsk, const uint8_t rng_key[32]) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  if (!rng_key) return fail(ctx, TFHE_HIP_EINVAL, "null generator key");
+  ChaChaKey k;
+  memcpy(k.k, rng_key, 32);
+  const int rc = gen_cloud_key_locked(ctx, key_lv0, key_lv1, alpha_ksk, alpha_bsk, k);
+  volatile uint32_t *wipe = k.k;
+  for (int i = 0; i < 8; ++i) wipe[i] = 0;
+  return rc;
+}
+
+int tfhe_hip_gen_cloud_key_secure(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint32_t *key_lv1,
+                                  double alpha_ksk, double alpha_bsk) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  uint8_t buf[32];
+  size_t got = 0;
+  while (got < sizeof(buf)) {  // the kernel's CSPRNG, as the reference's thread_rng is seeded (OsRng)
+    const ssize_t r = getrandom(buf + got, sizeof(buf) - got, 0);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      std::lock_guard<std::mutex> lk(ctx->mu);
+      return fail(ctx, TFHE_HIP_EHIP, std::string("getrandom: ") + strerror(errno));
+    }
+    got += (size_t)r;
+  }
+  const int rc = tfhe_hip_gen_cloud_key_with_key(ctx, key_lv0, key_lv1, alpha_ksk, alpha_bsk, buf);
+  volatile uint8_t *wipe = buf;
+  for (size_t i = 0; i < sizeof(buf); ++i) wipe[i] = 0;
+  return rc;
+}
+
 
 int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uint32_t *decomp_offset,
                               uint32_t *testvec) {
@@ -659,6 +727,38 @@ int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uin
     HIPCHK(ctx, hipMemcpyAsync(testvec, ctx->d_testvec, 2 * kN * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_cloud_key_buffers(tfhe_hip_ctx *ctx, void **bsk, size_t *bsk_bytes, void **ksk, size_t *ksk_bytes,
+                               void **testvec, size_t *testvec_bytes, uint32_t *decomp_offset) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  const tfhe_hip_params &P = ctx->P;
+  const size_t bb = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
+  const size_t kb = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
+  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bb));
+  if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, kb + 4096));
+  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
+  if (bsk) *bsk = ctx->d_bsk;
+  if (bsk_bytes) *bsk_bytes = bb;
+  if (ksk) *ksk = ctx->d_ksk;
+  if (ksk_bytes) *ksk_bytes = kb;
+  if (testvec) *testvec = ctx->d_testvec;
+  if (testvec_bytes) *testvec_bytes = 2 * kN * 4;
+  if (decomp_offset) *decomp_offset = ctx->offset;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  if (!ctx->d_bsk || !ctx->d_ksk || !ctx->d_testvec)
+    return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_adopt_cloud_key before tfhe_hip_cloud_key_buffers");
+  // whatever filled the buffers (a peer copy, an RCCL broadcast on another stream) must have finished
+  HIPCHK(ctx, hipDeviceSynchronize());
+  ctx->offset = decomp_offset;
+  ctx->key_loaded = true;
   return TFHE_HIP_OK;
 }
 
@@ -1029,3 +1129,4 @@ int tfhe_hip_synchronize(tfhe_hip_ctx *ctx) {
 }
 
 }  // extern "C"
+#include "pool.hpp"

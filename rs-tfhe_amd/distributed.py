@@ -110,6 +110,29 @@ def broadcast_cloud_key(cloud_key_or_none, params, src: int = 0):
                     fields["blind_rotate_testvec"])
 
 
+def broadcast_engine_key(engine, src: int = 0) -> None:
+    """Replicate the cloud key held by rank `src`'s engine into every other rank's engine, device to device:
+    the three key buffers are broadcast IN PLACE in the engine layouts (RCCL over xGMI under the "nccl" backend),
+    so nothing is converted twice and nothing passes through host memory."""
+    import torch
+    import torch.distributed as dist
+
+    bsk, ksk, tv, off = engine.cloud_key_device_tensors()
+    offt = torch.tensor([off], dtype=torch.int64, device=bsk.device)
+    if dist.get_backend() == "nccl":
+        for t in (bsk, ksk, tv, offt):
+            dist.broadcast(t, src=src)
+    else:  # gloo moves host memory: stage (plumbing tests on boxes with fewer GPUs than ranks)
+        for t in (bsk, ksk, tv, offt):
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            if dist.get_rank() != src:
+                t.copy_(h)
+    torch.cuda.synchronize()
+    if dist.get_rank() != src:
+        engine.adopt_cloud_key(int(offt.item()))
+
+
 def sharded_batch_gate(engine, gate: int, a_shard, b_shard, out_shard, stream=None) -> None:
     """Each rank bootstraps its own shard; no exchange inside the computation."""
     engine.batch_gate_dev(gate, a_shard, b_shard, out_shard, stream)

@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import numpy as np
@@ -54,6 +55,9 @@ class Engine:
             raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._ctx = ctx
         self._key = None  # the CloudKey object currently loaded (held, so identity cannot be recycled)
+        # held by bootstrap.keyed_engine() across "make this key current" + the launch that needs it
+        self.lock = threading.RLock()
+        self._last_use = 0
 
     # -- lifetime -------------------------------------------------------------
     def close(self) -> None:
@@ -96,21 +100,29 @@ class Engine:
         )
         self._key = cloud_key
 
-    def gen_cloud_key(self, key_lv0, key_lv1, seed: int, alpha_ksk=None, alpha_bsk=None) -> None:
-        """CloudKey::new(&secret_key) (src/key.rs:59-66) on the GPU, straight into this context."""
+    def gen_cloud_key(self, key_lv0, key_lv1, seed=None, alpha_ksk=None, alpha_bsk=None, rng_key: bytes = None) -> None:
+        """CloudKey::new(&secret_key) (src/key.rs:59-66) on the GPU, straight into this context.
+
+        seed=None (default): masks and noise come from a ChaCha20 stream keyed by the operating system's CSPRNG
+        (`tfhe_hip_gen_cloud_key_secure`), or by the caller's 32-byte `rng_key`.  An integer `seed` makes the key
+        reproducible and as guessable as the seed: tests and benchmarks only (include/tfhe_hip.h)."""
         p = self.params
         k0, k1 = _u32(key_lv0).reshape(-1), _u32(key_lv1).reshape(-1)
         if len(k0) != p.n or len(k1) != N:
             raise ValueError("secret key has the wrong size for these parameters")
-        self._chk(
-            self._lib.tfhe_hip_gen_cloud_key(
-                self._ctx, _ptr(k0), _ptr(k1),
-                C.c_double(p.alpha_lv0 if alpha_ksk is None else alpha_ksk),
-                C.c_double(p.alpha_lv1 if alpha_bsk is None else alpha_bsk),
-                C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF),
-            )
-        )
-        self._key = ("generated", seed)
+        a0 = C.c_double(p.alpha_lv0 if alpha_ksk is None else alpha_ksk)
+        a1 = C.c_double(p.alpha_lv1 if alpha_bsk is None else alpha_bsk)
+        if rng_key is not None:
+            if seed is not None or len(rng_key) != 32:
+                raise ValueError("rng_key is 32 bytes and excludes seed")
+            buf = (C.c_uint8 * 32).from_buffer_copy(bytes(rng_key))
+            self._chk(self._lib.tfhe_hip_gen_cloud_key_with_key(self._ctx, _ptr(k0), _ptr(k1), a0, a1, C.addressof(buf)))
+        elif seed is None:
+            self._chk(self._lib.tfhe_hip_gen_cloud_key_secure(self._ctx, _ptr(k0), _ptr(k1), a0, a1))
+        else:
+            self._chk(self._lib.tfhe_hip_gen_cloud_key(self._ctx, _ptr(k0), _ptr(k1), a0, a1,
+                                                       C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)))
+        self._key = ("generated", object())
 
     def export_cloud_key(self):
         """The context's key back as a CloudKey in the reference layouts."""
@@ -123,6 +135,30 @@ class Engine:
         off = C.c_uint32(0)
         self._chk(self._lib.tfhe_hip_export_cloud_key(self._ctx, _ptr(bsk), _ptr(ksk), C.byref(off), _ptr(tv)))
         return CloudKey(p, bsk, ksk, int(off.value), tv)
+
+    def cloud_key_device_tensors(self):
+        """(bsk, ksk, testvec, decomposition_offset): the context's key buffers in the engine layouts as uint8 torch
+        tensors that ALIAS them (no copy), for device-to-device replication (`distributed.broadcast_engine_key`)."""
+        import torch
+
+        ptrs = [C.c_void_p() for _ in range(3)]
+        sizes = [C.c_size_t() for _ in range(3)]
+        off = C.c_uint32(0)
+        self._chk(self._lib.tfhe_hip_cloud_key_buffers(self._ctx, C.byref(ptrs[0]), C.byref(sizes[0]), C.byref(ptrs[1]),
+                                                       C.byref(sizes[1]), C.byref(ptrs[2]), C.byref(sizes[2]), C.byref(off)))
+
+        class _Alias:  # CUDA array interface: torch wraps the pointer without copying
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        dev = torch.device("cuda", self.device)
+        ts = [torch.as_tensor(_Alias(int(p.value), int(n.value)), device=dev) for p, n in zip(ptrs, sizes)]
+        return ts[0], ts[1], ts[2], int(off.value)
+
+    def adopt_cloud_key(self, decomposition_offset: int) -> None:
+        """The key buffers were filled from outside (see cloud_key_device_tensors): make them the current key."""
+        self._chk(self._lib.tfhe_hip_adopt_cloud_key(self._ctx, C.c_uint32(int(decomposition_offset))))
+        self._key = ("adopted", object())
 
     def ensure_key(self, cloud_key) -> None:
         if self._key is not cloud_key:
@@ -368,3 +404,131 @@ class Engine:
 
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))
+
+
+class Pool:
+    """Several GPUs behind one handle (`tfhe_hip_pool`): the reference's Rayon `par_map` over the ciphertexts of
+    a batch (src/parallel/rayon_impl.rs:40-47) as a map over devices.  `devices` may repeat an index (two
+    contexts on one GPU).  The cloud key goes to the first device once and is replicated device to device;
+    every batch call splits its host arrays contiguously over the members and keeps input order."""
+
+    def __init__(self, params: SecurityParams, devices):
+        self.params = params
+        self.devices = [int(d) for d in devices]
+        self._lib = _capi.lib()
+        cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
+        arr = (C.c_int * len(self.devices))(*self.devices)
+        h = C.c_void_p()
+        rc = self._lib.tfhe_hip_pool_create(C.byref(cp), arr, len(self.devices), C.byref(h))
+        if rc != _capi.OK:
+            msg = self._lib.tfhe_hip_pool_last_error(None)
+            raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.tfhe_hip_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __len__(self) -> int:
+        return int(self._lib.tfhe_hip_pool_size(self._h))
+
+    def _chk(self, rc: int) -> None:
+        if rc != _capi.OK:
+            msg = self._lib.tfhe_hip_pool_last_error(self._h)
+            raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+
+    def shard(self, count: int, member: int) -> tuple:
+        lo, hi = C.c_size_t(0), C.c_size_t(0)
+        self._lib.tfhe_hip_pool_shard(count, member, len(self), C.byref(lo), C.byref(hi))
+        return int(lo.value), int(hi.value)
+
+    # -- cloud key ------------------------------------------------------------
+    def load_cloud_key(self, cloud_key) -> None:
+        p = self.params
+        bsk = np.ascontiguousarray(cloud_key.bootstrapping_key, dtype=np.float64)
+        ksk, tv = _u32(cloud_key.key_switching_key), _u32(cloud_key.blind_rotate_testvec)
+        if bsk.size != p.n * 2 * p.l * 2 * N or ksk.size != N * p.iks_t * p.base * (p.n + 1) or tv.size != 2 * N:
+            raise ValueError("cloud key has the wrong size for these parameters")
+        self._chk(self._lib.tfhe_hip_pool_load_cloud_key(self._h, _ptr(bsk), _ptr(ksk),
+                                                         C.c_uint32(int(cloud_key.decomposition_offset)), _ptr(tv)))
+
+    def gen_cloud_key(self, key_lv0, key_lv1, seed=None) -> None:
+        """seed=None: generator keyed by the OS (tfhe_hip_pool_gen_cloud_key_secure); an integer: tests only."""
+        p = self.params
+        k0, k1 = _u32(key_lv0).reshape(-1), _u32(key_lv1).reshape(-1)
+        if len(k0) != p.n or len(k1) != N:
+            raise ValueError("secret key has the wrong size for these parameters")
+        a0, a1 = C.c_double(p.alpha_lv0), C.c_double(p.alpha_lv1)
+        if seed is None:
+            self._chk(self._lib.tfhe_hip_pool_gen_cloud_key_secure(self._h, _ptr(k0), _ptr(k1), a0, a1))
+        else:
+            self._chk(self._lib.tfhe_hip_pool_gen_cloud_key(self._h, _ptr(k0), _ptr(k1), a0, a1,
+                                                            C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)))
+
+    def export_cloud_key(self, member: int = 0):
+        from .key import CloudKey
+
+        p = self.params
+        bsk = np.empty((p.n, 2 * p.l, 2, N), np.float64)
+        ksk = np.empty((N, p.iks_t, p.base, p.n + 1), np.uint32)
+        tv = np.empty((2, N), np.uint32)
+        off = C.c_uint32(0)
+        self._chk(self._lib.tfhe_hip_pool_export_cloud_key(self._h, member, _ptr(bsk), _ptr(ksk), C.byref(off), _ptr(tv)))
+        return CloudKey(p, bsk, ksk, int(off.value), tv)
+
+    # -- batched hot path, host arrays ------------------------------------------
+    def _cts(self, a) -> np.ndarray:
+        return _u32(a).reshape(-1, self.params.n + 1)
+
+    def batch_gate(self, gate: int, a, b=None) -> np.ndarray:
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if bb is not None and bb.shape != a.shape:
+            raise ValueError("operand batches differ in shape")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_pool_batch_gate(self._h, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
+        return out
+
+    def batch_gates_mixed(self, gates, a, b) -> np.ndarray:
+        a, b = self._cts(a), self._cts(b)
+        g = np.ascontiguousarray(gates, dtype=np.uint8).reshape(-1)
+        if len(g) != len(a) or b.shape != a.shape:
+            raise ValueError("gates / operand batches differ in length")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_pool_batch_gates_mixed(self._h, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
+        return out
+
+    def batch_bootstrap(self, cts, testvec=None, keyswitch: bool = True) -> np.ndarray:
+        cts = self._cts(cts)
+        out = np.empty_like(cts)
+        per_ct, tv = 0, None
+        if testvec is not None:
+            tv = _u32(testvec)
+            per_ct = int(tv.ndim == 3)
+            if tv.size != (len(cts) if per_ct else 1) * 2 * N:
+                raise ValueError("testvec must be [2][N] or [count][2][N]")
+        self._chk(self._lib.tfhe_hip_pool_batch_bootstrap(self._h, _ptr(cts), _ptr(tv), per_ct, int(keyswitch), _ptr(out),
+                                                          len(cts)))
+        return out
+
+    def batch_mux(self, a, b, c, naive: bool) -> np.ndarray:
+        a, b, c = self._cts(a), self._cts(b), self._cts(c)
+        if not (a.shape == b.shape == c.shape):
+            raise ValueError("operand batches differ in shape")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_pool_batch_mux(self._h, int(bool(naive)), _ptr(a), _ptr(b), _ptr(c), _ptr(out), len(a)))
+        return out
+
+    def batch_blind_rotate(self, cts, testvec=None) -> np.ndarray:
+        cts = self._cts(cts)
+        tv = _u32(testvec) if testvec is not None else None
+        out = np.empty((len(cts), 2, N), np.uint32)
+        self._chk(self._lib.tfhe_hip_pool_batch_blind_rotate(self._h, _ptr(cts), _ptr(tv), _ptr(out), len(cts)))
+        return out

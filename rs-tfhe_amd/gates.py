@@ -10,19 +10,14 @@ from __future__ import annotations
 import numpy as np
 
 from . import engine as E
-from .bootstrap import Bootstrap, HipBootstrap, default_bootstrap, engine_for, _params_of
+from .bootstrap import Bootstrap, HipBootstrap, default_bootstrap, keyed_engine
 from .params import f64_to_torus
-
-
-def _eng(cloud_key, device: int = 0) -> E.Engine:
-    eng = engine_for(_params_of(cloud_key), device)
-    eng.ensure_key(cloud_key)
-    return eng
 
 
 def _gate(gate: int, a, b, cloud_key, device: int = 0):
     a = np.asarray(a, dtype=np.uint32)
-    out = _eng(cloud_key, device).batch_gate(gate, a, b)
+    with keyed_engine(cloud_key, device) as eng:  # key choice + launch: one critical section
+        out = eng.batch_gate(gate, a, b)
     return out[0] if a.ndim == 1 else out
 
 
@@ -85,12 +80,14 @@ class Gates:
 
     def mux(self, a, b, c, cloud_key):  # gates.rs:157-183 (reference formula)
         a = np.asarray(a, dtype=np.uint32)
-        out = _eng(cloud_key, getattr(self.bootstrap, "device", 0)).batch_mux(a, b, c, naive=False)
+        with keyed_engine(cloud_key, getattr(self.bootstrap, "device", 0)) as eng:
+            out = eng.batch_mux(a, b, c, naive=False)
         return out[0] if a.ndim == 1 else out
 
     def mux_naive(self, a, b, c, cloud_key):  # gates.rs:189-199
         a = np.asarray(a, dtype=np.uint32)
-        out = _eng(cloud_key, getattr(self.bootstrap, "device", 0)).batch_mux(a, b, c, naive=True)
+        with keyed_engine(cloud_key, getattr(self.bootstrap, "device", 0)) as eng:
+            out = eng.batch_mux(a, b, c, naive=True)
         return out[0] if a.ndim == 1 else out
 
     def not_(self, a):  # gates.rs:202-204 (no bootstrap)
@@ -133,4 +130,5 @@ def batch_xnor(inputs_a, inputs_b, cloud_key, device: int = 0): return _gate(E.X
 
 def batch_blind_rotate(srcs, cloud_key, device: int = 0):
     """trgsw::batch_blind_rotate (src/trgsw.rs:289-294): [count][n+1] -> [count][2][N]."""
-    return _eng(cloud_key, device).batch_blind_rotate(srcs)
+    with keyed_engine(cloud_key, device) as eng:
+        return eng.batch_blind_rotate(srcs)

@@ -20,8 +20,9 @@ def gen_testvec() -> np.ndarray:
 
 class CloudKey:
     @classmethod
-    def new(cls, secret_key, seed: int = 0, device: int = 0) -> "CloudKey":
-        """CloudKey::new(&secret_key), src/key.rs:59-66."""
+    def new(cls, secret_key, seed=None, device: int = 0) -> "CloudKey":
+        """CloudKey::new(&secret_key), src/key.rs:59-66.  seed=None draws the generator key from the OS;
+        an integer seed is for reproducible tests only (see client.SecretKey.cloud_key)."""
         return secret_key.cloud_key(seed, device)
 
     def __init__(self, params: SecurityParams, bootstrapping_key, key_switching_key,

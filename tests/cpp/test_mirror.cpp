@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <thread>
 
 #include "rs_tfhe_hip.hpp"
 
@@ -165,10 +166,10 @@ int main() {
   {
     rs_tfhe::SecretKey sk = rs_tfhe::SecretKey::generate(P, 4242);
     CHECK(sk.key_lv0.size() == (size_t)P.n && sk.key_lv1.size() == N, "secret key sizes");
-    CloudKey gk = generate_cloud_key(sk, 77);
+    CloudKey gk = generate_cloud_key_seeded(sk, 77);
     CHECK(gk.decomposition_offset == 0x82080000u, "generated key: decomposition offset");
     CHECK(gk.blind_rotate_testvec.b[5] == 0x20000000u && gk.blind_rotate_testvec.a[5] == 0, "generated key: test vector");
-    std::mt19937_64 rng(5);
+    ChaChaRng rng(5);
     Gates g;
     for (int a = 0; a < 2; ++a)
       for (int b = 0; b < 2; ++b) {
@@ -204,6 +205,62 @@ int main() {
     *slot = cloud_key;  // the oracle-generated key for `key`, same address
     CHECK(decrypt_bool(g.nand(encrypt_bool(true, P, key), encrypt_bool(false, P, key), *slot), key) == true, "address reuse re-uploads");
     delete slot;
+
+    // ---- two threads, two keys, alternating (bootstrap/mod.rs:23: strategies are Send + Sync and every call
+    // names its &CloudKey): each thread must always compute under ITS key.  A shared context whose key is
+    // checked and then used in two steps fails this; with_key + one resident context per key passes it.
+    {
+      rs_tfhe::SecretKey sk2 = rs_tfhe::SecretKey::generate(P, 999);
+      CloudKey gk2 = generate_cloud_key_seeded(sk2, 78);
+      std::atomic<int> bad{0};
+      auto worker = [&](const rs_tfhe::SecretKey &s, const CloudKey &k, uint64_t seed) {
+        ChaChaRng r(seed);
+        Gates gg;
+        for (int it = 0; it < 6; ++it) {
+          const bool a = (it & 1) != 0, b = (it & 2) != 0;
+          Ciphertext ca = tlwe::encrypt_bool(a, P.alpha_lv0, s.key_lv0, r), cb = tlwe::encrypt_bool(b, P.alpha_lv0, s.key_lv0, r);
+          if (tlwe::decrypt_bool(gg.nand(ca, cb, k), s.key_lv0) != !(a && b)) ++bad;
+          gates::Pairs in{{ca, cb}, {cb, ca}, {ca, ca}};
+          auto out = gates::batch_xor(in, k);
+          if (tlwe::decrypt_bool(out[0], s.key_lv0) != (a != b) || tlwe::decrypt_bool(out[2], s.key_lv0) != false) ++bad;
+        }
+      };
+      std::thread t1(worker, std::cref(sk), std::cref(gk), 11), t2(worker, std::cref(sk2), std::cref(gk2), 12);
+      t1.join();
+      t2.join();
+      CHECK(bad.load() == 0, "two threads with two alternating keys: %d wrong results", bad.load());
+    }
+    // several devices behind one handle (here: two contexts on GPU 0): same words as the single-context path,
+    // in input order, at a count that does not divide evenly
+    {
+      DevicePool pool(P, {0, 0});
+      CHECK(pool.size() == 2, "pool size");
+      pool.load(gk);
+      ChaChaRng r(21);
+      gates::Pairs in;
+      std::vector<bool> want;
+      for (int i = 0; i < 7; ++i) {
+        const bool a = (i % 3) == 0, b = (i & 1) != 0;
+        in.push_back({tlwe::encrypt_bool(a, P.alpha_lv0, sk.key_lv0, r), tlwe::encrypt_bool(b, P.alpha_lv0, sk.key_lv0, r)});
+        want.push_back(!(a && b));
+      }
+      auto one = gates::batch_nand(in, gk);
+      auto two = pool.batch_gate(TFHE_HIP_NAND, in);
+      bool same = one.size() == two.size();
+      for (size_t i = 0; same && i < one.size(); ++i) same = one[i].p == two[i].p && tlwe::decrypt_bool(two[i], sk.key_lv0) == want[i];
+      CHECK(same, "pool of two contexts equals the single-context batch word for word");
+    }
+    // OS-keyed generation (the default): a usable key, different every time
+    {
+      rs_tfhe::SecretKey sk3 = rs_tfhe::SecretKey::generate(P);
+      CloudKey k3 = generate_cloud_key(sk3), k4 = generate_cloud_key(sk3);
+      CHECK(k3.key_switching_key != k4.key_switching_key, "OS-keyed generation must differ from call to call");
+      ChaChaRng r3;
+      Ciphertext ca = tlwe::encrypt_bool(true, P.alpha_lv0, sk3.key_lv0, r3), cb = tlwe::encrypt_bool(true, P.alpha_lv0, sk3.key_lv0, r3);
+      CHECK(tlwe::decrypt_bool(Gates().nand(ca, cb, k3), sk3.key_lv0) == false, "nand under an OS-keyed cloud key");
+      ChaChaRng a1(7), a2(7), a3(8);
+      CHECK(a1() == a2() && a1() != a3(), "ChaChaRng(seed) is reproducible");
+    }
   }
   std::printf(failures ? "%d FAILURES\n" : "all C++ mirror tests passed (%d failures)\n", failures);
   return failures ? 1 : 0;

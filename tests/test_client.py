@@ -79,3 +79,28 @@ def test_encrypt_round_trip_and_noise(O, C):
     assert np.array_equal(sk4.decrypt_lwe_message(sk4.encrypt_lwe_message(msgs + 32, 16, seed=13), 16), msgs)
     with pytest.raises(ValueError):
         C.SecretKey(P, np.full(700, 2), np.zeros(1024))
+
+
+def test_default_randomness_is_the_os_csprng(O, C):
+    """seed=None (the default of SecretKey.new / encrypt_* / cloud_key) draws from os.urandom, as the reference's
+    thread_rng is OS-seeded (tlwe.rs:38): keys and ciphertexts differ from call to call, the distributions are
+    the reference's (uniform bits / words, N(0, alpha) noise on the torus)."""
+    import rs_tfhe_amd as R
+
+    P = R.params.SECURITY_128_BIT
+    assert isinstance(C._rng(None), C.OsRng) and isinstance(C._rng(5), np.random.Generator)
+    a, b = C.SecretKey.new(P), C.SecretKey.new(P)
+    assert not np.array_equal(a.key_lv0, b.key_lv0) and not np.array_equal(a.key_lv1, b.key_lv1)
+    assert set(np.unique(a.key_lv1)) == {0, 1} and 400 < int(a.key_lv1.sum()) < 624  # 6.9 sigma of Binomial(1024, 1/2)
+    bits = np.random.default_rng(1).integers(0, 2, 8192).astype(bool)
+    c1, c2 = a.encrypt_bool(bits), a.encrypt_bool(bits)
+    assert not np.array_equal(c1, c2)
+    assert np.array_equal(a.decrypt_bool(c1), bits) and np.array_equal(a.decrypt_bool(c2), bits)
+    err = (a.phase(c1) - C.f64_to_torus(np.where(bits, 0.125, -0.125))).view(np.int32).astype(np.float64)
+    sigma = P.alpha_lv0 * 2**32
+    assert abs(err.mean()) < 6 * sigma / np.sqrt(len(err)) and 0.95 < err.std() / sigma < 1.05
+    # Box-Muller tails: about 0.27 % beyond 3 sigma
+    g = C.OsRng().normal(0.0, 1.0, 200001)
+    assert len(g) == 200001 and abs(g.mean()) < 0.02 and 0.98 < g.std() < 1.02 and 0.0015 < (np.abs(g) > 3).mean() < 0.0045
+    w = C.OsRng().integers(0, 1 << 32, (64, 700))
+    assert w.shape == (64, 700) and len(np.unique(w)) > 44000 and abs(w.mean() / 2**31 - 1) < 0.02

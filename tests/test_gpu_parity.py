@@ -666,6 +666,119 @@ def test_gpu_key_generation(O, keys128):
     eng2.close()
 
 
+def _chacha20_block(key_words, counter, nonce_words):
+    """RFC 8439 section 2.3 block function (pure Python), the checker for the device keystream."""
+    def rotl(x, r):
+        return ((x << r) | (x >> (32 - r))) & 0xFFFFFFFF
+
+    st = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574] + list(key_words) + [counter] + list(nonce_words)
+    x = list(st)
+
+    def qr(a, b, c, d):
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 16)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 12)
+        x[a] = (x[a] + x[b]) & 0xFFFFFFFF; x[d] = rotl(x[d] ^ x[a], 8)
+        x[c] = (x[c] + x[d]) & 0xFFFFFFFF; x[b] = rotl(x[b] ^ x[c], 7)
+
+    for _ in range(10):
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15)
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14)
+    return [(a + b) & 0xFFFFFFFF for a, b in zip(x, st)]
+
+
+@pytest.mark.gpu
+def test_gpu_key_generation_randomness(O, keys128):
+    """The generator behind tfhe_hip_gen_cloud_key_{secure,with_key}: mask words are the RFC 8439 ChaCha20
+    keystream under the 256-bit generator key (checked against the RFC's own test vector and a pure-Python block
+    function), the OS-keyed default gives a different key every call, and keys made either way are ordinary keys."""
+    import rs_tfhe_amd as R
+
+    # RFC 8439 section 2.3.2 test vector pins the checker itself
+    kw = [int.from_bytes(bytes(range(4 * i, 4 * i + 4)), "little") for i in range(8)]
+    blk = _chacha20_block(kw, 1, [0x09000000, 0x4A000000, 0x00000000])
+    assert blk[0] == 0xE4E7F110 and blk[15] == 0x4E3C50A2
+
+    sk, _ = keys128
+    P = R.params.SECURITY_128_BIT
+    eng = R.Engine(P, 0)
+    rng_key = bytes(range(100, 132))
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, rng_key=rng_key)
+    k1 = eng.export_cloud_key()
+    words = [int.from_bytes(rng_key[4 * i:4 * i + 4], "little") for i in range(8)]
+    base = P.base
+    for (i, j, k) in ((0, 0, 1), (7, 2, 3), (1023, P.iks_t - 1, base - 1)):
+        row = base * P.iks_t * i + base * j + k
+        for x16 in (0, 5, 43):  # mask words 16*x16 .. 16*x16+15 of the row = keystream block x16, nonce (row, 0, "KSK")
+            want = _chacha20_block(words, x16, [row, 0, 0x4B534B])
+            got = k1.key_switching_key[i, j, k, 16 * x16:min(16 * x16 + 16, P.n)]  # word n is the body, not a mask word
+            assert got.tolist() == want[:len(got)], (i, j, k, x16)
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, rng_key=rng_key)
+    assert np.array_equal(eng.export_cloud_key().key_switching_key, k1.key_switching_key)  # the generator key fixes the key
+    # default: keyed by getrandom(2) -- two calls, two keys; and it works as a key
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1)
+    s1 = eng.export_cloud_key()
+    eng.gen_cloud_key(sk.key_lv0, sk.key_lv1)
+    s2 = eng.export_cloud_key()
+    assert not np.array_equal(s1.key_switching_key, s2.key_switching_key)
+    assert not np.array_equal(s1.bootstrapping_key, s2.bootstrapping_key)
+    assert not np.array_equal(s1.key_switching_key, k1.key_switching_key)
+    A = np.array([1, 1, 0, 0, 1, 0, 1], bool)
+    B = np.array([1, 0, 1, 0, 1, 1, 0], bool)
+    ca, cb = sk.encrypt_bool(A, 5), sk.encrypt_bool(B, 6)
+    assert np.array_equal(sk.decrypt_bool(eng.batch_gate(O.GATE_NAND, ca, cb)), ~(A & B))
+    with pytest.raises(ValueError):
+        eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, rng_key=b"short")
+    eng.close()
+
+
+# ---- several devices behind one handle --------------------------------------------------------------
+def test_pool_two_contexts_bit_exact_and_order_preserving(O, eng128, keys128):
+    """tfhe_hip_pool with devices = {0, 0} (two contexts on the one GPU of the test box; the driver's 8-GPU run
+    uses {0..7}): the key is uploaded once and replicated device to device, every batch call splits the host
+    arrays contiguously over the members (rayon_impl.rs:40-47 keeps input order) -- results must equal the
+    single-context ones word for word at ragged counts, including counts below the member count."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    P = pk.params
+    pool = R.Pool(P, [0, 0])
+    assert len(pool) == 2 and pool.shard(5, 0) == (0, 3) and pool.shard(5, 1) == (3, 5)
+    pool.load_cloud_key(pk)
+    k0, k1 = pool.export_cloud_key(0), pool.export_cloud_key(1)
+    assert np.array_equal(k1.bootstrapping_key, k0.bootstrapping_key) and np.array_equal(k1.key_switching_key, k0.key_switching_key)
+    assert np.array_equal(k1.key_switching_key, pk.key_switching_key) and k1.decomposition_offset == pk.decomposition_offset
+    rng = np.random.default_rng(77)
+    for count in (1, 2, 5, 37, 700):
+        A, B, Cc = (rng.integers(0, 2, count).astype(bool) for _ in range(3))
+        ca, cb, cc = sk.encrypt_bool(A, 100 + count), sk.encrypt_bool(B, 200 + count), sk.encrypt_bool(Cc, 300 + count)
+        got = pool.batch_gate(O.GATE_NAND, ca, cb)
+        assert np.array_equal(got, eng128.batch_gate(O.GATE_NAND, ca, cb)), count
+        assert np.array_equal(sk.decrypt_bool(got), ~(A & B))
+        codes = rng.integers(0, 11, count).astype(np.uint8)
+        assert np.array_equal(pool.batch_gates_mixed(codes, ca, cb), eng128.batch_gates_mixed(codes, ca, cb))
+        assert np.array_equal(pool.batch_bootstrap(ca), eng128.batch_bootstrap(ca))
+        tv = rng.integers(0, 2**32, (count, 2, N), dtype=np.uint64).astype(np.uint32)  # per-ciphertext test vectors follow their shard
+        assert np.array_equal(pool.batch_bootstrap(ca, tv), eng128.batch_bootstrap(ca, tv))
+        assert np.array_equal(pool.batch_bootstrap(ca, tv[0], keyswitch=False), eng128.batch_bootstrap(ca, tv[0], keyswitch=False))
+        assert np.array_equal(pool.batch_mux(ca, cb, cc, naive=True), eng128.batch_mux(ca, cb, cc, naive=True))
+        assert np.array_equal(pool.batch_mux(ca, cb, cc, naive=False), eng128.batch_mux(ca, cb, cc, naive=False))
+        assert np.array_equal(pool.batch_blind_rotate(ca), eng128.batch_blind_rotate(ca))
+    assert pool.batch_gate(O.GATE_NAND, np.empty((0, P.n + 1), np.uint32), np.empty((0, P.n + 1), np.uint32)).shape == (0, P.n + 1)
+    # key generation through the pool: every member holds the same generated key
+    pool.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=5)
+    g0, g1 = pool.export_cloud_key(0), pool.export_cloud_key(1)
+    assert np.array_equal(g0.key_switching_key, g1.key_switching_key) and np.array_equal(g0.bootstrapping_key, g1.bootstrapping_key)
+    A = rng.integers(0, 2, 9).astype(bool)
+    ca = sk.encrypt_bool(A, 1)
+    assert np.array_equal(sk.decrypt_bool(pool.batch_gate(O.GATE_NAND, ca, ca)), ~A)
+    with pytest.raises(R._capi.TfheHipError):
+        pool.batch_gate(99, ca, ca)
+    pool.close()
+    with pytest.raises(R._capi.TfheHipError):
+        R.Pool(P, [0, 4096])  # no such device: create fails as a whole
+
+
 # ---- golden fixture (no oracle involved) -----------------------------------------------------
 def test_golden_toy_instance(golden):
     import rs_tfhe_amd as R
