@@ -128,7 +128,8 @@ def broadcast_engine_key(engine, src: int = 0) -> None:
             dist.broadcast(h, src=src)
             if dist.get_rank() != src:
                 t.copy_(h)
-    torch.cuda.synchronize()
+    if bsk.is_cuda:
+        torch.cuda.synchronize(bsk.device)
     if dist.get_rank() != src:
         engine.adopt_cloud_key(int(offt.item()))
 

@@ -54,6 +54,26 @@ def _worker(rank, world, port, q):
         rng = np.random.default_rng(0)
         ok = ok and np.array_equal(rep.bootstrapping_key, rng.standard_normal((4, 2, 2, 1024)))
         ok = ok and rep.decomposition_offset == 0x80000000 and rep.key_switching_key.shape == (1024, 2, 4, 5)
+        # in-place replication of the engine-layout key buffers (bench.py's multi-rank path; RCCL on GPUs)
+        class FakeEngine:
+            def __init__(self, fill):
+                g = torch.Generator().manual_seed(5)
+                self.bufs = [torch.randint(0, 255, (n,), dtype=torch.uint8, generator=g) if fill
+                             else torch.zeros(n, dtype=torch.uint8) for n in (4096, 1024, 64)]
+                self.off = 0x82080000 if fill else 0
+                self.adopted = None
+
+            def cloud_key_device_tensors(self):
+                return self.bufs[0], self.bufs[1], self.bufs[2], self.off
+
+            def adopt_cloud_key(self, off):
+                self.adopted = off
+
+        fe = FakeEngine(rank == 0)
+        D.broadcast_engine_key(fe, src=0)
+        want = FakeEngine(True)
+        ok = ok and all(torch.equal(a, b) for a, b in zip(fe.bufs, want.bufs))
+        ok = ok and fe.adopted == (None if rank == 0 else 0x82080000)
         # barrier + max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -968,7 +968,26 @@ def test_rccl_backend_single_rank(O, keys128):
         got = full.cpu().numpy().view(np.uint32)
         assert np.array_equal(got, O.batch_gate(ck, O.GATE_NAND, ca, cb))
         assert np.array_equal(sk.decrypt_bool(got), ~(A & B))
+        # device-to-device key replication in the engine layouts (what bench.py's multi-rank path does): the
+        # broadcast runs in place on the aliased key buffers; a second context then receives them by a plain
+        # device copy + adopt, and must compute the same words
+        D.broadcast_engine_key(eng, src=0)
+        eng2 = R.Engine(pk.params, 0)
+        src_t, dst_t = eng.cloud_key_device_tensors(), eng2.cloud_key_device_tensors()
+        assert src_t[0].numel() == pk.params.bsk_bytes and src_t[0].data_ptr() != dst_t[0].data_ptr()
+        for a_, b_ in zip(src_t[:3], dst_t[:3]):
+            b_.copy_(a_)
+        torch.cuda.synchronize()
+        eng2.adopt_cloud_key(src_t[3])
+        assert np.array_equal(eng2.batch_gate(O.GATE_NAND, ca, cb), got)
+        k2 = eng2.export_cloud_key()
+        assert np.array_equal(k2.key_switching_key, pk.key_switching_key) and k2.decomposition_offset == pk.decomposition_offset
+        eng3 = R.Engine(pk.params, 0)
+        with pytest.raises(R._capi.TfheHipError):
+            eng3.adopt_cloud_key(0)  # no buffers yet
         eng.close()
+        eng2.close()
+        eng3.close()
     finally:
         dist.destroy_process_group()
 
