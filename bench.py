@@ -128,15 +128,18 @@ def main():
     tc = torch.from_numpy(cc.view(np.int32)).to(dev) if cc is not None else None
     tlut = torch.from_numpy(lut.poly.view(np.int32)).to(dev) if lut is not None else None
 
+    xor_codes = torch.full((B - B // 2,), R.engine.XOR, dtype=torch.uint8, device=dev) if args.gate == "mixed" else None
+
     def step():
         if args.gate == "pbs":
             eng.batch_bootstrap_dev(ta, to, testvec=tlut)
         elif args.gate.startswith("mux"):
             eng.batch_mux_dev(ta, tb, tc, to, naive=(args.gate == "mux_naive"))
         elif args.gate == "mixed":  # BASELINE configs[4]: half hom_mux (reference formula), half hom_xor
-            h = B // 2
-            eng.batch_mux_dev(ta[:h], tb[:h], tc[:h], to[:h], naive=False)
-            eng.batch_gate_dev(R.engine.XOR, ta[h:], tb[h:], to[h:])
+            h = B // 2                # one circuit level: two blind-rotation launches + one key switch in all
+            mo, xo = R.circuit.mux_and_gates_dev(eng, ta[:h], tb[:h], tc[:h], xor_codes, ta[h:], tb[h:])
+            to[:h].copy_(mo)
+            to[h:].copy_(xo)
         else:
             eng.batch_gate_dev(gate, ta, tb, to)
 

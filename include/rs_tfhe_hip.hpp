@@ -61,6 +61,12 @@ constexpr SecurityParams SECURITY_110_BIT{110, 630, 3, 6, 2, 8, 3.0517578125e-05
 constexpr SecurityParams SECURITY_128_BIT{128, 700, 3, 6, 2, 9, 2.0e-5, 2.0e-8};                // :379-404
 constexpr SecurityParams SECURITY_UINT1{1, 700, 2, 10, 2, 8, 2.0e-05, 2.0e-08};                 // :148-173
 constexpr SecurityParams SECURITY_UINT4{4, 820, 1, 22, 5, 3, 0.0000025167616095979554, 2.220446049250313e-16};  // :235-260
+constexpr SecurityParams SECURITY_UINT2{2, 687, 1, 18, 4, 3, 0.00002120846893069972, 0.0000000000023184122752704995};   // :177-202
+constexpr SecurityParams SECURITY_UINT3{3, 820, 1, 23, 6, 2, 0.0000025167616095979554, 2.220446049250313e-16};  // :206-231
+constexpr SecurityParams SECURITY_UINT5{5, 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17};      // :264-289
+constexpr SecurityParams SECURITY_UINT6{6, 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17};      // :293-318
+constexpr SecurityParams SECURITY_UINT7{7, 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17};    // :322-347
+constexpr SecurityParams SECURITY_UINT8{8, 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17};    // :351-376
 constexpr SecurityParams DEFAULT_SECURITY = SECURITY_128_BIT;                                    // :411
 
 // ---- src/utils.rs:9-16 -----------------------------------------------------------

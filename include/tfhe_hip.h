@@ -177,6 +177,17 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
 int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a,
                                    const uint32_t *b, uint32_t *out, size_t count, void *stream);
 
+/* The same per-ciphertext gates ending in bootstrap_without_key_switch (bootstrap/mod.rs:31-35): the output is
+ * sample_extract_index_2 of the rotated accumulator, [count][n+1] (trlwe.rs:122-136; needs n <= N).  This is the
+ * first level of Gates::mux (gates.rs:165-177: and(a, b) and and(not(a), c) without key switch) for a whole batch in
+ * ONE launch -- gates = AND for the first operand pairs, ANDNY for the second; the second level (or(u1, u2),
+ * gates.rs:179-182) is a tfhe_hip_batch_gates_mixed launch that can carry other gates of the same circuit level
+ * beside it.  Same gate-code rules as above. */
+int tfhe_hip_batch_gates_mixed_nks(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                   uint32_t *out, size_t count);
+int tfhe_hip_batch_gates_mixed_nks_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                       uint32_t *out, size_t count, void *stream);
+
 /* Replaces: Bootstrap::bootstrap / bootstrap_without_key_switch
  * (src/bootstrap/vanilla.rs:40-63) and LutBootstrap::bootstrap_lut
  * (src/bootstrap/lut.rs:79-99), mapped over a batch.

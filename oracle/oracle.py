@@ -84,9 +84,12 @@ SECURITY_UINT4 = Params("SECURITY_UINT4", 820, 1, 22, 5, 3, 0.000002516761609597
 SECURITY_UINT2 = Params("SECURITY_UINT2", 687, 1, 18, 4, 3, 0.00002120846893069972, 0.0000000000023184122752704995)
 SECURITY_UINT3 = Params("SECURITY_UINT3", 820, 1, 23, 6, 2, 0.0000025167616095979554, 2.220446049250313e-16)
 SECURITY_UINT5 = Params("SECURITY_UINT5", 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17)
+SECURITY_UINT6 = Params("SECURITY_UINT6", 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17)  # params.rs:293-318
 SECURITY_UINT7 = Params("SECURITY_UINT7", 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17)
+SECURITY_UINT8 = Params("SECURITY_UINT8", 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17)  # params.rs:351-376
 PARAM_SETS = {p.name: p for p in (SECURITY_80_BIT, SECURITY_110_BIT, SECURITY_128_BIT, SECURITY_UINT1, SECURITY_UINT2,
-                                  SECURITY_UINT3, SECURITY_UINT4, SECURITY_UINT5, SECURITY_UINT7)}
+                                  SECURITY_UINT3, SECURITY_UINT4, SECURITY_UINT5, SECURITY_UINT6,
+                                  SECURITY_UINT7, SECURITY_UINT8)}
 
 # gate op codes -- shared with include/tfhe_hip.h
 GATE_NAND, GATE_OR, GATE_AND, GATE_XOR, GATE_XNOR, GATE_NOR, GATE_ANDNY, GATE_ANDYN, GATE_ORNY, GATE_ORYN, GATE_COPY = range(11)

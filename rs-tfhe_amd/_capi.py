@@ -67,6 +67,8 @@ SIGNATURES = {
     "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_gates_mixed": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_gates_mixed_dev": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_batch_gates_mixed_nks": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_batch_gates_mixed_nks_dev": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_bootstrap": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ]),
     "tfhe_hip_batch_bootstrap_dev": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ, _P]),
     "tfhe_hip_batch_tlwe_lincomb": (C.c_int, [_CTX, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32, _P, _SZ]),

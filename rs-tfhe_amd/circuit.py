@@ -101,15 +101,19 @@ class Circuit:
 
         n_in, B, w = inputs.shape
         assert n_in == self.n_inputs
-        wires = torch.empty((self.n_wires, B, w), dtype=torch.int32, device=inputs.device)
-        wires[:n_in] = inputs
-        for ia, ib, io, codes in self._plan(inputs.device):
-            a = wires.index_select(0, ia).reshape(-1, w)
-            b = wires.index_select(0, ib).reshape(-1, w)
-            gc = codes.repeat_interleave(B).contiguous()
-            out = torch.empty_like(a)
-            eng.batch_gates_mixed_dev(gc, a, b, out, stream)
-            wires.index_copy_(0, io, out.reshape(len(io), B, w))
+        # the gathers, the temporaries' allocations and the engine's kernels must share ONE stream: make `stream`
+        # torch's current stream for the duration (a kernel on another stream would race the index_select that
+        # feeds it, and the caching allocator could hand a temporary to someone else while it is still in use)
+        with _on_stream(stream):
+            wires = torch.empty((self.n_wires, B, w), dtype=torch.int32, device=inputs.device)
+            wires[:n_in] = inputs
+            for ia, ib, io, codes in self._plan(inputs.device):
+                a = wires.index_select(0, ia).reshape(-1, w)
+                b = wires.index_select(0, ib).reshape(-1, w)
+                gc = codes.repeat_interleave(B).contiguous()
+                out = torch.empty_like(a)
+                eng.batch_gates_mixed_dev(gc, a, b, out)  # torch's current stream = `stream`
+                wires.index_copy_(0, io, out.reshape(len(io), B, w))
         return wires
 
     def _plan(self, device):
@@ -151,6 +155,15 @@ class Circuit:
         return wires
 
 
+def _on_stream(stream):
+    """torch.cuda.stream(stream) when a stream is given, a no-op context otherwise."""
+    import contextlib
+
+    import torch
+
+    return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+
 # ---- LUT arithmetic: the nibble adder of examples/lut_add_two_numbers.rs, batched ---------------
 def lut_add_u8_dev(eng: E.Engine, a_low, a_high, b_low, b_high, stream=None):
     """8-bit addition with three programmable bootstraps per byte pair instead of eight gate
@@ -169,17 +182,40 @@ def lut_add_u8_dev(eng: E.Engine, a_low, a_high, b_low, b_high, stream=None):
 
     gen = Generator(32)  # message modulus 32 covers every possible nibble sum 0..30 (:86-87)
     dev = a_low.device
-    lut_mod16 = torch.from_numpy(gen.generate_lookup_table(lambda x: x % 16).poly.view(np.int32)).to(dev)
-    lut_carry = torch.from_numpy(gen.generate_lookup_table(lambda x: 1 if x >= 16 else 0).poly.view(np.int32)).to(dev)
-    sum_low, carry = torch.empty_like(a_low), torch.empty_like(a_low)
-    high, sum_high = torch.empty_like(a_low), torch.empty_like(a_low)
-    # bootstraps 1 and 2: low sum mod 16 and its carry, both from a_low + b_low (:124-150)
-    eng.batch_lincomb_bootstrap_dev(1, a_low, 1, b_low, 0, sum_low, testvec=lut_mod16, stream=stream)
-    eng.batch_lincomb_bootstrap_dev(1, a_low, 1, b_low, 0, carry, testvec=lut_carry, stream=stream)
-    # a_high + b_high (:152-153), then bootstrap 3 on (a_high + b_high) + carry (:155-158)
-    eng.batch_tlwe_lincomb_dev(1, a_high, 1, b_high, 0, high, stream=stream)
-    eng.batch_lincomb_bootstrap_dev(1, high, 1, carry, 0, sum_high, testvec=lut_mod16, stream=stream)
+    with _on_stream(stream):  # uploads, allocations and kernels on one stream (see Circuit.run_dev)
+        lut_mod16 = torch.from_numpy(gen.generate_lookup_table(lambda x: x % 16).poly.view(np.int32)).to(dev)
+        lut_carry = torch.from_numpy(gen.generate_lookup_table(lambda x: 1 if x >= 16 else 0).poly.view(np.int32)).to(dev)
+        sum_low, carry = torch.empty_like(a_low), torch.empty_like(a_low)
+        high, sum_high = torch.empty_like(a_low), torch.empty_like(a_low)
+        # bootstraps 1 and 2: low sum mod 16 and its carry, both from a_low + b_low (:124-150)
+        eng.batch_lincomb_bootstrap_dev(1, a_low, 1, b_low, 0, sum_low, testvec=lut_mod16)
+        eng.batch_lincomb_bootstrap_dev(1, a_low, 1, b_low, 0, carry, testvec=lut_carry)
+        # a_high + b_high (:152-153), then bootstrap 3 on (a_high + b_high) + carry (:155-158)
+        eng.batch_tlwe_lincomb_dev(1, a_high, 1, b_high, 0, high)
+        eng.batch_lincomb_bootstrap_dev(1, high, 1, carry, 0, sum_high, testvec=lut_mod16)
     return sum_low, sum_high, carry
+
+
+def mux_and_gates_dev(eng: E.Engine, a, b, c, codes, xa, xb, stream=None):
+    """One circuit level holding `M` Gates::mux (the reference's formula, src/gates.rs:157-183) beside `X` two-input
+    gates (`codes`: uint8 device tensor [X]) -- BASELINE configs[4] is M hom_mux + X hom_xor -- in TWO blind-rotation
+    launches and ONE key switch whatever M and X:
+      launch 1  [and(a, b) | and(not(a), c)] for all M, bootstrap_without_key_switch      (gates.rs:165-177)
+      launch 2  [or(u1, u2) for all M | the X other gates], full bootstrap                   (gates.rs:179-182)
+    a, b, c: int32 CUDA tensors [M][n+1]; xa, xb: [X][n+1].  Returns (mux_out [M][n+1], gate_out [X][n+1])."""
+    import torch
+
+    M, X = a.shape[0], xa.shape[0]
+    with _on_stream(stream):
+        g1 = torch.empty(2 * M, dtype=torch.uint8, device=a.device)
+        g1[:M] = E.AND
+        g1[M:] = E.ANDNY
+        u = torch.empty((2 * M, a.shape[1]), dtype=torch.int32, device=a.device)
+        eng.batch_gates_mixed_dev(g1, torch.cat([a, a]), torch.cat([b, c]), u, keyswitch=False)
+        g2 = torch.cat([torch.full((M,), E.OR, dtype=torch.uint8, device=a.device), codes])
+        out = torch.empty((M + X, a.shape[1]), dtype=torch.int32, device=a.device)
+        eng.batch_gates_mixed_dev(g2, torch.cat([u[:M], xa]), torch.cat([u[M:], xb]), out)
+    return out[:M], out[M:]
 
 
 def lut_add_u8(eng: E.Engine, a_low, a_high, b_low, b_high):

@@ -62,16 +62,18 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 //      in the forward-FFT bin order, ready for fft_inverse.  INIT0: the first row
 //      WRITES the accumulators (no zero fill, no add).
 //      (decomposition trgsw.rs:144-171, batch_ifft + fma_in_fd_1024 trgsw.rs:99-106)
-// TFHE_ROW_UNROLL: 0 = the digit-row loop stays a loop (smallest code), 1 = unrolled.
-#ifndef TFHE_ROW_UNROLL
-#define TFHE_ROW_UNROLL 0
-#endif
 // How many of the 8 a-half / b-half key loads of a row are issued before the forward FFT.
 #ifndef TFHE_PREFETCH_A
 #define TFHE_PREFETCH_A 8
 #endif
 #ifndef TFHE_PREFETCH_B
 #define TFHE_PREFETCH_B 4
+#endif
+// 1 = the inverse-pass-3 twiddles (20 VGPRs) are re-read from the cache-resident table before the inverse
+// transforms of each CMUX step instead of living in registers across the forward phase (measured: 432 vs 469 ms
+// on the round-2 kernel before the workgroup change, profiles/exp/logs/r2a_ab_fft_v2_and_ablations.log)
+#ifndef TFHE_RELOAD_I3
+#define TFHE_RELOAD_I3 1
 #endif
 // 1 = the two inverse transforms of a CMUX step are interleaved through the one tile (fft_inverse2)
 #ifndef TFHE_INV_PAIR
@@ -183,83 +185,11 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
   // The remaining rows stay a LOOP: with the body duplicated (or, at L = 2, the one-trip loop flattened)
   // the scheduler overlaps rows and spills; the trip count is hidden from it for that reason.
   int rows = L;
-  if (L > 1 && !TFHE_ROW_UNROLL) asm volatile("" : "+s"(rows));
-#if TFHE_ROW_UNROLL
-#pragma unroll
-#else
+  if (L > 1) asm volatile("" : "+s"(rows));
 #pragma unroll 1
-#endif
   for (int i = 1; i < rows; ++i)
     external_product_row<L, false>(half_sel * L + i, 32 - (i + 1) * bgbit, w_lo, w_hi, bsk_rsrc, bsk_i_off, tw, tile,
                                    lane, bgbit, fa_re, fa_im, fb_re, fb_im);
-}
-
-// ---- paired rows: two digit polynomials transformed together (fft_forward2), so that one's LDS
-// round trips are covered by the other's butterflies.  Rows r and r+1 may straddle the a / b halves
-// (L odd): each takes its digits from its own half's decomposition words.
-#ifndef TFHE_FWD_PAIR
-#define TFHE_FWD_PAIR 0
-#endif
-// 1 = the inverse-pass-3 twiddles (20 VGPRs) are re-read from the table before each inverse pair
-#ifndef TFHE_RELOAD_I3
-#define TFHE_RELOAD_I3 1
-#endif
-#ifndef TFHE_RELOAD_F3
-#define TFHE_RELOAD_F3 0
-#endif
-#ifndef TFHE_PAIR_SB
-#define TFHE_PAIR_SB 1
-#endif
-template <int L, bool INIT>
-__device__ __forceinline__ void external_product_row_pair(int rx, int shift_x, const uint32_t (&wx_lo)[8],
-                                                          const uint32_t (&wx_hi)[8], int shift_y,
-                                                          const uint32_t (&wy_lo)[8], const uint32_t (&wy_hi)[8],
-                                                          __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
-                                                          const Twiddles &tw, double2 *tile, int lane, int bgbit,
-                                                          double (&fa_re)[8], double (&fa_im)[8], double (&fb_re)[8],
-                                                          double (&fb_im)[8]) {
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-  const uint32_t row_x = bsk_i_off + (uint32_t)rx * (2u * kN2 * 16u), row_y = row_x + 2u * kN2 * 16u;
-  f64x2 va[8], vb[8];
-#ifndef TFHE_PAIR_PA
-#define TFHE_PAIR_PA 8
-#endif
-#pragma unroll
-  for (int s = 0; s < TFHE_PAIR_PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)s * 1024u);
-  double xr[8], xi[8], yr[8], yi[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    xr[m] = (double)sbfe(wx_lo[m], shift_x, bgbit);
-    xi[m] = (double)sbfe(wx_hi[m], shift_x, bgbit);
-    yr[m] = (double)sbfe(wy_lo[m], shift_y, bgbit);
-    yi[m] = (double)sbfe(wy_hi[m], shift_y, bgbit);
-  }
-  fft_forward2(xr, xi, yr, yi, tw, tile, lane);
-#if TFHE_PAIR_SB
-#define PAIR_SB() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PAIR_SB()
-#endif
-  PAIR_SB();  // keep the key loads below from being hoisted into the transforms (register pressure)
-#pragma unroll
-  for (int s = TFHE_PAIR_PA; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)s * 1024u);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_x + (uint32_t)(kN2 * 16 + s * 1024));
-#pragma unroll
-  for (int s = 0; s < 8; ++s) cmac<INIT>(fa_re[s], fa_im[s], xr[s], xi[s], va[s]);
-  PAIR_SB();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_y + (uint32_t)s * 1024u);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) cmac<INIT>(fb_re[s], fb_im[s], xr[s], xi[s], vb[s]);
-  PAIR_SB();
-#pragma unroll
-  for (int s = 0; s < 8; ++s) vb[s] = ldkey(bsk_rsrc, lane_off, row_y + (uint32_t)(kN2 * 16 + s * 1024));
-#pragma unroll
-  for (int s = 0; s < 8; ++s) cmac<false>(fa_re[s], fa_im[s], yr[s], yi[s], va[s]);
-#pragma unroll
-  for (int s = 0; s < 8; ++s) cmac<false>(fb_re[s], fb_im[s], yr[s], yi[s], vb[s]);
-  PAIR_SB();
 }
 
 struct BlindRotateArgs {
@@ -377,62 +307,6 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
     wg_sync<1>();
     const int k = s_abar[i];
     double fa_re[8], fa_im[8], fb_re[8], fb_im[8];  // written by the first row of the a half
-#if TFHE_FWD_PAIR
-    {
-#if TFHE_RELOAD_F3
-      {
-        int z = 0;
-        asm volatile("" : "+v"(z));
-        tw.reload_f3(A.tw, lane, z);
-      }
-#endif
-      // decomposition words of both halves: w = (X^k*acc - acc + offset) ^ signmask  (trgsw.rs:183-186, 144-171)
-      uint32_t wa_lo[8], wa_hi[8], wb_lo[8], wb_hi[8];
-      const uint32_t *pb_ = acc + kN;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int j = lane + 64 * m;
-        wa_lo[m] = (rot_read(acc, j, k) - acc[j] + offset) ^ signmask;
-        wa_hi[m] = (rot_read(acc, j + kN2, k) - acc[j + kN2] + offset) ^ signmask;
-      }
-      const uint32_t boff = (uint32_t)i * per_i_bytes;
-      const int bg = A.bgbit;
-      if (L == 1) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int j = lane + 64 * m;
-          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
-          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
-        }
-        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - bg, wb_lo, wb_hi, bsk_rsrc, boff, tw, tile,
-                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
-      } else if (L == 2) {
-        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - 2 * bg, wa_lo, wa_hi, bsk_rsrc, boff, tw, tile,
-                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int j = lane + 64 * m;
-          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
-          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
-        }
-        external_product_row_pair<L, false>(2, 32 - bg, wb_lo, wb_hi, 32 - 2 * bg, wb_lo, wb_hi, bsk_rsrc, boff, tw,
-                                            tile, lane, bg, fa_re, fa_im, fb_re, fb_im);
-      } else {
-        external_product_row_pair<L, true>(0, 32 - bg, wa_lo, wa_hi, 32 - 2 * bg, wa_lo, wa_hi, bsk_rsrc, boff, tw, tile,
-                                           lane, bg, fa_re, fa_im, fb_re, fb_im);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-          const int j = lane + 64 * m;
-          wb_lo[m] = (rot_read(pb_, j, k) - pb_[j] + offset) ^ signmask;
-          wb_hi[m] = (rot_read(pb_, j + kN2, k) - pb_[j + kN2] + offset) ^ signmask;
-        }
-        external_product_row_pair<L, false>(2, 32 - 3 * bg, wa_lo, wa_hi, 32 - bg, wb_lo, wb_hi, bsk_rsrc, boff, tw, tile,
-                                            lane, bg, fa_re, fa_im, fb_re, fb_im);
-        external_product_row_pair<L, false>(4, 32 - 2 * bg, wb_lo, wb_hi, 32 - 3 * bg, wb_lo, wb_hi, bsk_rsrc, boff, tw,
-                                            tile, lane, bg, fa_re, fa_im, fb_re, fb_im);
-      }
-    }
-#else
     // cmux: tmp = in2 - in1 = X^k*acc - acc (trgsw.rs:183-186), + decomposition offset; the a
     // half is consumed before the b half is formed, so only 16 of these are ever live
     {
@@ -458,7 +332,6 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
       external_product_half<L, false>(1, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane, A.bgbit,
                                       signmask, fa_re, fa_im, fb_re, fb_im);
     }
-#endif
 #if TFHE_RELOAD_I3
     {
       int z = 0;

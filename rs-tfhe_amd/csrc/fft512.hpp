@@ -110,14 +110,6 @@ struct Twiddles {
       i3[2 * q + 1] = a.y;
     }
   }
-  __device__ __forceinline__ void reload_f3(const double2 *__restrict__ tw, int lane, int opaque_zero) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      double2 a = tw[q * 64 + lane + opaque_zero];
-      f3[2 * q] = a.x;
-      f3[2 * q + 1] = a.y;
-    }
-  }
 };
 
 // Plain in-register 8-point DFT (no pre-twiddle).  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
@@ -416,33 +408,6 @@ __device__ __forceinline__ void fft_inverse2(double (&xr)[8], double (&xi)[8], d
   tpAi_read(yr, yi, tile, lane);
   inv_pass3(xr, xi, tw);
   inv_pass3(yr, yi, tw);
-}
-
-// Two independent forward transforms interleaved the same way.
-__device__ __forceinline__ void fft_forward2(double (&xr)[8], double (&xi)[8], double (&yr)[8], double (&yi)[8],
-                                             const Twiddles &tw, double2 *tile, int lane) {
-  fwd_pass1(xr, xi);
-  wave_lds_order();
-  tpA_write(xr, xi, tile, lane);
-  wave_lds_order();
-  tpA_read(xr, xi, tile, lane);
-  fwd_pass1(yr, yi);
-  wave_lds_order();
-  tpA_write(yr, yi, tile, lane);
-  wave_lds_order();
-  tpA_read(yr, yi, tile, lane);
-  fwd_pass2(xr, xi, tw, lane);
-  wave_lds_order();
-  tpB_write(xr, xi, tile, lane);
-  wave_lds_order();
-  tpB_read(xr, xi, tile, lane);
-  fwd_pass2(yr, yi, tw, lane);
-  wave_lds_order();
-  tpB_write(yr, yi, tile, lane);
-  wave_lds_order();
-  tpB_read(yr, yi, tile, lane);
-  fwd_pass3(xr, xi, tw);
-  fwd_pass3(yr, yi, tw);
 }
 
 #ifndef TFHE_FFT_HOST_EMU

@@ -365,6 +365,13 @@ int gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, 
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
 }
 
+// per-ciphertext gates, bootstrap_without_key_switch outputs (the first level of Gates::mux, gates.rs:165-177)
+int gates_mixed_nks_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b, uint32_t *out,
+                        size_t count, hipStream_t s) {
+  GatePrep gp{1u, 1u, 0u};
+  return launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, nullptr, out, gates);
+}
+
 int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec, int per_ct,
                   int keyswitch, uint32_t *out, size_t count, hipStream_t s) {
   GatePrep gp;
@@ -782,6 +789,15 @@ int tfhe_hip_batch_gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, cons
   return gates_mixed_dev(ctx, gates, a, b, out, count, pick(ctx, stream));
 }
 
+int tfhe_hip_batch_gates_mixed_nks_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                       uint32_t *out, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  CHK(need_key(ctx));
+  if (count && (!gates || !a || !b || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  return gates_mixed_nks_dev(ctx, gates, a, b, out, count, pick(ctx, stream));
+}
+
 int tfhe_hip_batch_bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                  int per_ct, int keyswitch, uint32_t *out, size_t count,
                                  void *stream) {
@@ -869,6 +885,25 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
   CHK(ensure(ctx, ctx->h_out, bytes));
   CHK(gates_mixed_dev(ctx, (const uint8_t *)ctx->h_idx.p, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p,
                       (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
+}
+
+int tfhe_hip_batch_gates_mixed_nks(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                   uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  CHK(need_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!gates || !a || !b || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  for (size_t i = 0; i < count; ++i)
+    if (gates[i] > TFHE_HIP_COPY) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, a, bytes));
+  CHK(to_dev(ctx, ctx->h_b, b, bytes));
+  CHK(to_dev(ctx, ctx->h_idx, gates, count));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(gates_mixed_nks_dev(ctx, (const uint8_t *)ctx->h_idx.p, (const uint32_t *)ctx->h_a.p, (const uint32_t *)ctx->h_b.p,
+                          (uint32_t *)ctx->h_out.p, count, ctx->stream));
   return to_host(ctx, out, ctx->h_out, bytes);
 }
 

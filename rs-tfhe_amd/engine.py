@@ -178,14 +178,15 @@ class Engine:
         self._chk(self._lib.tfhe_hip_batch_gate(self._ctx, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
         return out
 
-    def batch_gates_mixed(self, gates, a, b) -> np.ndarray:
+    def batch_gates_mixed(self, gates, a, b, keyswitch: bool = True) -> np.ndarray:
         """Per-ciphertext gate selectors (one launch for a whole circuit level)."""
         a, b = self._cts(a), self._cts(b)
         g = np.ascontiguousarray(gates, dtype=np.uint8).reshape(-1)
         if len(g) != len(a) or b.shape != a.shape:
             raise ValueError("gates / operand batches differ in length")
         out = np.empty_like(a)
-        self._chk(self._lib.tfhe_hip_batch_gates_mixed(self._ctx, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
+        fn = self._lib.tfhe_hip_batch_gates_mixed if keyswitch else self._lib.tfhe_hip_batch_gates_mixed_nks
+        self._chk(fn(self._ctx, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
         return out
 
     def batch_bootstrap(self, cts, testvec=None, keyswitch: bool = True) -> np.ndarray:
@@ -324,18 +325,18 @@ class Engine:
             self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream))
         )
 
-    def batch_gates_mixed_dev(self, gates, a, b, out, stream=None) -> None:
-        """gates: uint8 CUDA tensor [count]; a, b, out: int32 CUDA tensors [count][n+1]."""
+    def batch_gates_mixed_dev(self, gates, a, b, out, stream=None, keyswitch: bool = True) -> None:
+        """gates: uint8 CUDA tensor [count]; a, b, out: int32 CUDA tensors [count][n+1].  keyswitch=False ends
+        in bootstrap_without_key_switch (the first level of Gates::mux, `tfhe_hip_batch_gates_mixed_nks_dev`)."""
         if not gates.is_cuda or gates.element_size() != 1 or not gates.is_contiguous():
             raise ValueError("gates must be a contiguous uint8 CUDA tensor")
+        if gates.device.index != self.device:
+            raise ValueError("gates tensor lives on another device than this engine")
         count = self._dev_batch(a, b, out)
         if gates.numel() != count:
             raise ValueError("one gate code per ciphertext")
-        self._chk(
-            self._lib.tfhe_hip_batch_gates_mixed_dev(
-                self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream)
-            )
-        )
+        fn = self._lib.tfhe_hip_batch_gates_mixed_dev if keyswitch else self._lib.tfhe_hip_batch_gates_mixed_nks_dev
+        self._chk(fn(self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream)))
 
     def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:
         count = self._dev_batch(cts, out)

@@ -76,8 +76,12 @@ SECURITY_UINT3 = SecurityParams("SECURITY_UINT3", 3, 820, 1, 23, 6, 2, 0.0000025
 SECURITY_UINT4 = SecurityParams("SECURITY_UINT4", 4, 820, 1, 22, 5, 3, 0.0000025167616095979554, 2.220446049250313e-16)
 # src/params.rs:264-289
 SECURITY_UINT5 = SecurityParams("SECURITY_UINT5", 5, 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17)
+# src/params.rs:293-318 (same shapes as UINT5: message modulus 64 is a property of the encoder, not of the kernels)
+SECURITY_UINT6 = SecurityParams("SECURITY_UINT6", 6, 1071, 1, 22, 6, 3, 7.08822676541043e-8, 2.2204460492503131e-17)
 # src/params.rs:322-347
 SECURITY_UINT7 = SecurityParams("SECURITY_UINT7", 7, 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17)
+# src/params.rs:351-376 (same shapes as UINT7)
+SECURITY_UINT8 = SecurityParams("SECURITY_UINT8", 8, 1160, 1, 22, 7, 3, 1.9662200074984027e-8, 2.2204460492503131e-17)
 
 DEFAULT_SECURITY = SECURITY_128_BIT  # src/params.rs:411
 
@@ -92,7 +96,9 @@ PARAM_SETS = {
         SECURITY_UINT3,
         SECURITY_UINT4,
         SECURITY_UINT5,
+        SECURITY_UINT6,
         SECURITY_UINT7,
+        SECURITY_UINT8,
     )
 }
 

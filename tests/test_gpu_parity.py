@@ -94,6 +94,25 @@ def test_poly_mul_vs_schoolbook(O, eng128, golden):
     assert np.array_equal(got[:2], np.stack([g["kat_consistency_expected"], g["kat_dense_expected"]]))
 
 
+def test_stage_fft_rounds_half_away_from_zero(O, eng128):
+    """FFTProcessor::fft ends in f64::round (klemsa.rs:145-146): exact .5 ties go AWAY from zero.  A constant
+    spectrum x * ifft(delta_0) (and x * ifft(delta_512), the imaginary slot of the fold) comes back as exactly
+    x at one coefficient and exactly 0 elsewhere -- every intermediate is exact -- so x = k + 1/2 lands on a
+    tie.  tfhe_hip_batch_fft must agree with the reference semantics word for word (ties-to-even would give
+    0, 2, 2, 0, -2, -2 on the first six)."""
+    xs = np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 1e6 + 0.5, -1e6 - 0.5, 2.0**31 - 0.5, -(2.0**31) + 0.5, 3.0, -7.0])
+    want0 = [1, 2, 3, -1, -2, -3, 1000001, -1000001, -2**31, -2**31, 3, -7]
+    for pos in (0, N // 2):
+        delta = np.zeros(N, np.uint32)
+        delta[pos] = 1
+        unit = O.klemsa_ifft(delta)
+        spectra = xs[:, None] * unit[None, :]
+        ref = np.stack([O.klemsa_fft(sp) for sp in spectra])
+        assert ref[:, pos].view(np.int32).tolist() == want0 and not np.delete(ref, pos, axis=1).any()
+        got = eng128.batch_fft(spectra)
+        assert np.array_equal(got, ref), (pos, got[:, pos].view(np.int32).tolist())
+
+
 # ---- single stages ------------------------------------------------------------------------
 def test_external_product_exact_128(O, eng128, keys128):
     sk, ck = keys128
@@ -448,7 +467,7 @@ def test_full_size_pbs_uint4(O, keys_uint4):
     pk = _cloud_key(ck)
     eng = R.bootstrap.engine_for(pk.params, 0)
     eng.ensure_key(pk)
-    B, base = 65536, 512
+    B, base = 65536, 4096  # 4,096 distinct ciphertexts, tiled 16 times
     rng = np.random.default_rng(44)
     msgs0 = rng.integers(0, 16, base)
     cts0 = sk.encrypt_lwe_message(msgs0, 16, 4401)
@@ -482,7 +501,7 @@ def test_full_size_mixed_circuit_80bit(O, keys80):
     pk = _cloud_key(ck)
     eng = R.bootstrap.engine_for(pk.params, 0)
     eng.ensure_key(pk)
-    B, base = 65536, 256
+    B, base = 65536, 4096
     rng = np.random.default_rng(45)
     bits = rng.integers(0, 2, (3, base)).astype(bool)
     ins0 = np.stack([sk.encrypt_bool(bits[w], 4500 + w) for w in range(3)])  # [3][base][n+1]
@@ -502,6 +521,84 @@ def test_full_size_mixed_circuit_80bit(O, keys80):
         assert np.array_equal(out[:base], out[B - base:])
     ref = c.run_reference(lambda op, a, b: O.batch_gate(ck, op, a, b), ins0[:, :4])
     assert np.array_equal(wires[w_mux][:4].cpu().numpy().view(np.uint32), ref[w_mux])
+
+
+def test_configs4_share_mux_and_xor_80bit(O, keys80):
+    """BASELINE configs[4] exactly, per-GPU share of the 1M-gate batch: 131,072 gates at SECURITY_80_BIT, half
+    `Gates::mux` in the reference's own formula (gates.rs:157-183: two bootstrap_without_key_switch, add, one full
+    bootstrap -- quirk Q5: not a decryptable construction, reproduced bit for bit) and half hom_xor, all 327,680
+    input ciphertexts distinct, as ONE circuit level: two blind-rotation launches and one key switch
+    (circuit.mux_and_gates_dev).  Bar: slices from both ends of each half equal the CPU path word for word, the
+    whole mux half equals the gate-by-gate device path (batch_mux_dev) word for word, the xor half decrypts."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys80
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    M = X = 65536
+    rng = np.random.default_rng(48)
+    bits = rng.integers(0, 2, (5, M)).astype(bool)
+    a, b, c, xa, xb = (sk.encrypt_bool(bits[w], 4800 + w) for w in range(5))
+    dev = torch.device("cuda:0")
+    ta, tb, tc, txa, txb = (torch.from_numpy(x.view(np.int32)).to(dev) for x in (a, b, c, xa, xb))
+    codes = torch.full((X,), R.engine.XOR, dtype=torch.uint8, device=dev)
+    eng.kernel_times()
+    eng.set_profiling(True)
+    mo, xo = R.circuit.mux_and_gates_dev(eng, ta, tb, tc, codes, txa, txb)
+    torch.cuda.synchronize()
+    eng.set_profiling(False)
+    kt = eng.kernel_times()
+    assert kt["blind_rotate_launches"] == 2 and kt["key_switch_launches"] == 1 and kt["bootstraps"] == 2 * M + M + X
+    mux, xor = mo.cpu().numpy().view(np.uint32), xo.cpu().numpy().view(np.uint32)
+    sl = np.r_[0:24, M - 24:M]
+    assert np.array_equal(mux[sl], O.batch_mux(ck, a[sl], b[sl], c[sl], naive=False))
+    assert np.array_equal(xor[sl], O.batch_gate(ck, O.GATE_XOR, xa[sl], xb[sl]))
+    assert np.array_equal(sk.decrypt_bool(xor), bits[3] ^ bits[4])
+    ref = torch.empty_like(ta)
+    eng.batch_mux_dev(ta, tb, tc, ref, naive=False)
+    torch.cuda.synchronize()
+    assert torch.equal(ref, mo)
+    # the same level through the host-array entry points on a ragged slice (tfhe_hip_batch_gates_mixed_nks)
+    k = 37
+    g1 = np.r_[np.full(k, R.engine.AND), np.full(k, R.engine.ANDNY)].astype(np.uint8)
+    u = eng.batch_gates_mixed(g1, np.concatenate([a[:k], a[:k]]), np.concatenate([b[:k], c[:k]]), keyswitch=False)
+    assert np.array_equal(eng.batch_gate(R.engine.OR, u[:k], u[k:]), mux[:k])
+    with pytest.raises(R._capi.TfheHipError):
+        eng.batch_gates_mixed(np.full(2 * k, 11, np.uint8), np.concatenate([a[:k], a[:k]]), np.concatenate([b[:k], c[:k]]), keyswitch=False)
+
+
+def test_soak_gates_vs_cpu_path_128bit(O, eng128, keys128):
+    """Soak: every gate x many ciphertexts, a large batch through the LDS-ring key switch,
+    and uniformly random words instead of encryptions, against the CPU path under the same key: not one
+    ciphertext may differ in any word, every gate output decrypts to its truth table.  ~18 k bootstraps by
+    default (about half a minute of CPU checking on the box's cores); TFHE_SOAK_FULL=1 runs the 70,440 of the
+    round-1 one-off."""
+    import os
+
+    sk, ck = keys128
+    full = os.environ.get("TFHE_SOAK_FULL") == "1"
+    per_gate, big, rand = (4096, 16384, 4096) if full else (1024, 6144, 1024)
+    rng = np.random.default_rng(4700)
+    bad = 0
+    for op in range(10):
+        A, B = rng.integers(0, 2, per_gate).astype(bool), rng.integers(0, 2, per_gate).astype(bool)
+        ca, cb = sk.encrypt_bool(A, 47000 + 2 * op), sk.encrypt_bool(B, 47001 + 2 * op)
+        got = eng128.batch_gate(op, ca, cb)
+        bad += int((got != O.batch_gate(ck, op, ca, cb)).any(axis=1).sum())
+        want = np.array([O.GATE_TRUTH[op](bool(x), bool(y)) for x, y in zip(A, B)])
+        assert np.array_equal(sk.decrypt_bool(got), want), O.GATE_NAMES[op]
+    A, B = rng.integers(0, 2, big).astype(bool), rng.integers(0, 2, big).astype(bool)
+    ca, cb = sk.encrypt_bool(A, 47100), sk.encrypt_bool(B, 47101)
+    got = eng128.batch_gate(O.GATE_NAND, ca, cb)
+    bad += int((got != O.batch_gate(ck, O.GATE_NAND, ca, cb)).any(axis=1).sum())
+    assert np.array_equal(sk.decrypt_bool(got), ~(A & B))
+    ra = rng.integers(0, 2**32, (rand, 701), dtype=np.uint64).astype(np.uint32)  # not encryptions of anything
+    rb = rng.integers(0, 2**32, (rand, 701), dtype=np.uint64).astype(np.uint32)
+    bad += int((eng128.batch_gate(O.GATE_XOR, ra, rb) != O.batch_gate(ck, O.GATE_XOR, ra, rb)).any(axis=1).sum())
+    assert bad == 0, f"{bad} ciphertexts differ from the CPU path"
 
 
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
@@ -861,7 +958,7 @@ def test_device_resident_full_batch_properties(O, eng128, keys128):
     sk, ck = keys128
     B = 65536
     rng = np.random.default_rng(29)
-    base = 256
+    base = 4096  # distinct ciphertext pairs, tiled 16 times
     bits_a = rng.integers(0, 2, base).astype(bool)
     bits_b = rng.integers(0, 2, base).astype(bool)
     ca0, cb0 = sk.encrypt_bool(bits_a, 601), sk.encrypt_bool(bits_b, 602)

@@ -90,6 +90,35 @@ def test_param_sets_match_oracle_and_survey(O):
         assert P.f64_to_torus(d) == O.f64_to_torus(d)
 
 
+def test_param_sets_match_reference_source():
+    """Every SecurityParams constant of src/params.rs (11 sets, UINT6 / UINT8 included), parsed from the reference's
+    own source text where it lies, equals the product's table (and the C++ mirror's)."""
+    path = "/root/reference/src/params.rs"
+    if not os.path.exists(path):
+        pytest.skip("reference sources not present on this box")
+    from rs_tfhe_amd import params as P
+
+    src = re.sub(r"//[^\n]*", "", open(path).read()).replace("_", "")  # comments and digit separators out
+    found = {}
+    for m in re.finditer(r"pub const (SECURITY[A-Z0-9]+): SecurityParams = SecurityParams \{(.*?)\n\};", src, re.S):
+        body = m.group(2)
+        lv0 = re.search(r"tlwelv0: TlweParams \{\s*n: (\d+),\s*alpha: ([0-9.e+-]+)", body)
+        lv1 = re.search(r"tlwelv1: TlweParams \{\s*n: (\d+),\s*alpha: ([0-9.e+-]+)", body)
+        g = re.search(r"trgswlv1: TrgswParams \{(.*?)\}", body, re.S).group(1)
+        f = {k: re.search(rf"\b{k}: ([0-9.e+-]+)", g).group(1) for k in ("n", "bgbit", "l", "basebit", "ikst")}
+        name = m.group(1).replace("SECURITY", "SECURITY_").replace("BIT", "_BIT")
+        found[name] = (int(lv0.group(1)), int(f["l"]), int(f["bgbit"]), int(f["basebit"]), int(f["ikst"]),
+                       float(lv0.group(2)), float(lv1.group(2)), int(f["n"]))
+    assert len(found) == 11, sorted(found)
+    hdr = open(os.path.join(ROOT, "include", "rs_tfhe_hip.hpp")).read()
+    for name, (n, l, bgbit, basebit, t, a0, a1, N) in found.items():
+        pp = P.PARAM_SETS[name]
+        assert (pp.n, pp.l, pp.bgbit, pp.basebit, pp.iks_t, pp.alpha_lv0, pp.alpha_lv1) == (n, l, bgbit, basebit, t, a0, a1), name
+        assert N == 1024
+        cpp = re.search(rf"constexpr SecurityParams {name}\{{(.*?)\}};", hdr).group(1).split(",")
+        assert [int(x) for x in cpp[1:6]] == [n, l, bgbit, basebit, t] and float(cpp[6]) == a0 and float(cpp[7]) == a1, name
+
+
 def test_lut_generator_matches_oracle(O):
     from rs_tfhe_amd.lut import Encoder, Generator, div_round
 
