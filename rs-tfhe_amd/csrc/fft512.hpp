@@ -115,8 +115,14 @@ struct Twiddles {
 // Plain in-register 8-point DFT (no pre-twiddle).  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
 // The two 1/sqrt2 twiddles are not applied where they arise: their common factor H is
 // carried to the last stage and folded into its add/sub as FMAs (X = b +- H*q).  52 instructions.
+// Timing-only ablation (results wrong by construction): TFHE_ABL_NOFFT removes the butterflies (the data
+// still makes every LDS round trip and meets every key word).
+#ifndef TFHE_ABL_NOFFT
+#define TFHE_ABL_NOFFT 0
+#endif
 template <bool INV>
 __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
+  if (TFHE_ABL_NOFFT) return;
   constexpr double H = 0.70710678118654752440084436210485;
   double a0r = re[0] + re[4], a0i = im[0] + im[4];
   double a4r = re[0] - re[4], a4i = im[0] - im[4];
@@ -195,6 +201,7 @@ template <bool INV, bool SCALE = false>
 __device__ __forceinline__ void sdft8(double (&re)[8], double (&im)[8], double c4r, double c4i, double c2r,
                                       double c2i, double c1r, double c1i, double cwr, double cwi,
                                       double gr = 1.0, double gi = 0.0) {
+  if (TFHE_ABL_NOFFT) return;
   if (SCALE) {
     cmul<false>(re[0], im[0], gr, gi);
     cmul<false>(re[2], im[2], gr, gi);
@@ -244,7 +251,6 @@ __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcn
 // order, so a write may follow the reads of the same tile without a wait; the compiler's own
 // s_waitcnt protects the registers.
 __device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory"); }
-
 // compile-time constants of pass 1: c1 = exp(i*pi/16): c1^4 = exp(i*pi/4), c1^2 = exp(i*pi/8),
 // c1*W8 = exp(-3*i*pi/16)
 constexpr double kP1c4 = 0.70710678118654752440084436210485;
@@ -253,6 +259,43 @@ constexpr double kP1c4 = 0.70710678118654752440084436210485;
 #ifndef TFHE_ABL_NOLDS
 #define TFHE_ABL_NOLDS 0
 #endif
+// Timing-only ablation (results wrong by construction): TFHE_ABL_TPB_DPP replaces the LDS round trip of
+// transpose B (the exchange inside 8-lane groups) by the instruction mix a cross-lane version would issue --
+// three exchange stages over the 32 dwords a lane holds: lane bit 5 by 16 v_permlane32_swap, lane bit 4 by
+// 16 v_permlane16_swap, lane bit 3 by 48 DPP moves (row_ror:8 under bank masks needs a temporary per pair).
+// It answers "would DPP / permlane transposes be faster than LDS ones?" without building the re-indexed FFT.
+#ifndef TFHE_ABL_TPB_DPP
+#define TFHE_ABL_TPB_DPP 0
+#endif
+#ifndef TFHE_FFT_HOST_EMU
+__device__ __forceinline__ void abl_crosslane_exchange(double (&re)[8], double (&im)[8]) {
+  uint32_t w[32];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    w[4 * i] = (uint32_t)__double2loint(re[i]);
+    w[4 * i + 1] = (uint32_t)__double2hiint(re[i]);
+    w[4 * i + 2] = (uint32_t)__double2loint(im[i]);
+    w[4 * i + 3] = (uint32_t)__double2hiint(im[i]);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(w[i]), "+v"(w[i + 16]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(w[2 * i]), "+v"(w[2 * i + 1]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    uint32_t t;
+    asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "=v"(t) : "v"(w[i]), "0"(w[i + 16]));
+    asm volatile("v_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(w[i]) : "v"(w[i + 16]));
+    asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0x3" : "+v"(w[i + 16]) : "v"(t));
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    re[i] = __hiloint2double((int)w[4 * i + 1], (int)w[4 * i]);
+    im[i] = __hiloint2double((int)w[4 * i + 3], (int)w[4 * i + 2]);
+  }
+}
+#endif
+
 // ---- the two transposes, as separable halves so that two transforms can be interleaved ---------
 // A: write (k1, l) at k1*72 + l ; read lane (k1', l1) slot l2 at k1'*72 + l1 + 8*l2
 // B: write (k1, k2, l1) at k1*72 + k2*9 + l1 ; read lane (k1, k2') slot l1 at k1*72 + k2'*9 + l1
@@ -272,13 +315,19 @@ __device__ __forceinline__ void tpA_read(double (&re)[8], double (&im)[8], const
   }
 }
 __device__ __forceinline__ void tpB_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
-  if (TFHE_ABL_NOLDS) return;
+  if (TFHE_ABL_NOLDS || TFHE_ABL_TPB_DPP) return;
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int k = 0; k < 8; ++k) tile[hi * kPlane + k * 9 + lo] = make_double2(re[k], im[k]);
 }
 __device__ __forceinline__ void tpB_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
   if (TFHE_ABL_NOLDS) return;
+#ifndef TFHE_FFT_HOST_EMU
+  if (TFHE_ABL_TPB_DPP) {
+    abl_crosslane_exchange(re, im);
+    return;
+  }
+#endif
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
@@ -289,13 +338,19 @@ __device__ __forceinline__ void tpB_read(double (&re)[8], double (&im)[8], const
 }
 // the inverse transposes are the same maps with the roles of write and read exchanged
 __device__ __forceinline__ void tpBi_write(const double (&re)[8], const double (&im)[8], double2 *tile, int lane) {
-  if (TFHE_ABL_NOLDS) return;
+  if (TFHE_ABL_NOLDS || TFHE_ABL_TPB_DPP) return;
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int s = 0; s < 8; ++s) tile[hi * kPlane + lo * 9 + s] = make_double2(re[s], im[s]);
 }
 __device__ __forceinline__ void tpBi_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
   if (TFHE_ABL_NOLDS) return;
+#ifndef TFHE_FFT_HOST_EMU
+  if (TFHE_ABL_TPB_DPP) {
+    abl_crosslane_exchange(re, im);
+    return;
+  }
+#endif
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {

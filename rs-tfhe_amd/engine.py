@@ -306,6 +306,13 @@ class Engine:
         # context's own stream", so name the null stream explicitly: hipStreamLegacy == (hipStream_t)1
         return C.c_void_p(stream.cuda_stream or 1)
 
+    def _tp(self, t):
+        """Device pointer of a tensor that must live on this engine's GPU (test vectors, outputs, gate codes)."""
+        p = _tptr(t)
+        if t is not None and t.device.index != self.device:
+            raise ValueError(f"device tensor lives on {t.device}, the engine on cuda:{self.device}")
+        return p
+
     def _dev_batch(self, *tensors, width=None) -> int:
         """All tensors are [count][width] on this engine's GPU; returns count."""
         width = self.params.n + 1 if width is None else width
@@ -322,7 +329,7 @@ class Engine:
     def batch_gate_dev(self, gate: int, a, b, out, stream=None) -> None:
         count = self._dev_batch(a, b, out)
         self._chk(
-            self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream))
+            self._lib.tfhe_hip_batch_gate_dev(self._ctx, int(gate), self._tp(a), self._tp(b), self._tp(out), count, self._stream_ptr(stream))
         )
 
     def batch_gates_mixed_dev(self, gates, a, b, out, stream=None, keyswitch: bool = True) -> None:
@@ -336,7 +343,7 @@ class Engine:
         if gates.numel() != count:
             raise ValueError("one gate code per ciphertext")
         fn = self._lib.tfhe_hip_batch_gates_mixed_dev if keyswitch else self._lib.tfhe_hip_batch_gates_mixed_nks_dev
-        self._chk(fn(self._ctx, C.c_void_p(gates.data_ptr()), _tptr(a), _tptr(b), _tptr(out), count, self._stream_ptr(stream)))
+        self._chk(fn(self._ctx, C.c_void_p(gates.data_ptr()), self._tp(a), self._tp(b), self._tp(out), count, self._stream_ptr(stream)))
 
     def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None) -> None:
         count = self._dev_batch(cts, out)
@@ -344,14 +351,14 @@ class Engine:
             raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
         self._chk(
             self._lib.tfhe_hip_batch_bootstrap_dev(
-                self._ctx, _tptr(cts), _tptr(testvec), int(per_ct), int(keyswitch), _tptr(out), count, self._stream_ptr(stream)
+                self._ctx, self._tp(cts), self._tp(testvec), int(per_ct), int(keyswitch), self._tp(out), count, self._stream_ptr(stream)
             )
         )
 
     def batch_tlwe_lincomb_dev(self, ca: int, a, cb: int, b, cconst: int, out, stream=None) -> None:
         count = self._dev_batch(a, b, out)
         self._chk(self._lib.tfhe_hip_batch_tlwe_lincomb_dev(
-            self._ctx, ca & 0xFFFFFFFF, _tptr(a), cb & 0xFFFFFFFF, _tptr(b), cconst & 0xFFFFFFFF, _tptr(out), count,
+            self._ctx, ca & 0xFFFFFFFF, self._tp(a), cb & 0xFFFFFFFF, self._tp(b), cconst & 0xFFFFFFFF, self._tp(out), count,
             self._stream_ptr(stream)))
 
     def batch_lincomb_bootstrap_dev(self, ca: int, a, cb: int, b, cconst: int, out, testvec=None,
@@ -360,8 +367,8 @@ class Engine:
         if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
             raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
         self._chk(self._lib.tfhe_hip_batch_lincomb_bootstrap_dev(
-            self._ctx, ca & 0xFFFFFFFF, _tptr(a), cb & 0xFFFFFFFF, _tptr(b), cconst & 0xFFFFFFFF, _tptr(testvec),
-            int(per_ct), int(keyswitch), _tptr(out), count, self._stream_ptr(stream)))
+            self._ctx, ca & 0xFFFFFFFF, self._tp(a), cb & 0xFFFFFFFF, self._tp(b), cconst & 0xFFFFFFFF, self._tp(testvec),
+            int(per_ct), int(keyswitch), self._tp(out), count, self._stream_ptr(stream)))
 
     def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None) -> None:
         count = self._dev_batch(cts)
@@ -369,7 +376,7 @@ class Engine:
             raise ValueError("out_trlwe must be [count][2][N], testvec [2][N]")
         self._chk(
             self._lib.tfhe_hip_batch_blind_rotate_dev(
-                self._ctx, _tptr(cts), _tptr(testvec), _tptr(out_trlwe), count, self._stream_ptr(stream)
+                self._ctx, self._tp(cts), self._tp(testvec), self._tp(out_trlwe), count, self._stream_ptr(stream)
             )
         )
 
@@ -377,7 +384,7 @@ class Engine:
         count = self._dev_batch(a, b, c, out)
         self._chk(
             self._lib.tfhe_hip_batch_mux_dev(
-                self._ctx, int(naive), _tptr(a), _tptr(b), _tptr(c), _tptr(out), count, self._stream_ptr(stream)
+                self._ctx, int(naive), self._tp(a), self._tp(b), self._tp(c), self._tp(out), count, self._stream_ptr(stream)
             )
         )
 

@@ -601,6 +601,35 @@ def test_soak_gates_vs_cpu_path_128bit(O, eng128, keys128):
     assert bad == 0, f"{bad} ciphertexts differ from the CPU path"
 
 
+def test_bad_gate_code_on_the_device_is_reported(O, eng128, keys128):
+    """tfhe_hip_batch_gates_mixed_dev cannot read the codes on the host: a code outside tfhe_hip_gate is treated as
+    COPY by the kernel AND raises a device-side flag that the next tfhe_hip_synchronize returns as EINVAL (once).
+    The host-array entry point rejects the same batch up front."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    A = np.array([1, 0, 1, 1, 0], bool)
+    ca, cb = sk.encrypt_bool(A, 4900), sk.encrypt_bool(~A, 4901)
+    dev = torch.device("cuda:0")
+    ta, tb = torch.from_numpy(ca.view(np.int32)).to(dev), torch.from_numpy(cb.view(np.int32)).to(dev)
+    to = torch.empty_like(ta)
+    eng128.synchronize()
+    codes = torch.tensor([O.GATE_NAND, 200, O.GATE_XOR, 11, O.GATE_COPY], dtype=torch.uint8, device=dev)
+    eng128.batch_gates_mixed_dev(codes, ta, tb, to)
+    with pytest.raises(R._capi.TfheHipError, match="gate code"):
+        eng128.synchronize()
+    eng128.synchronize()  # reported once
+    out = to.cpu().numpy().view(np.uint32)
+    good = eng128.batch_gates_mixed(np.array([O.GATE_NAND, O.GATE_COPY, O.GATE_XOR, O.GATE_COPY, O.GATE_COPY], np.uint8), ca, cb)
+    assert np.array_equal(out, good)
+    with pytest.raises(R._capi.TfheHipError):
+        eng128.batch_gates_mixed(codes.cpu().numpy(), ca, cb)
+    eng128.batch_gates_mixed_dev(torch.zeros(5, dtype=torch.uint8, device=dev), ta, tb, to)
+    eng128.synchronize()  # a clean launch leaves no flag behind
+
+
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
     """Batches <= #CUs go through the 2l-waves-per-ciphertext latency kernel, larger ones through the
     one-wave-per-ciphertext batch kernel: both must give the oracle's bits, for every output form."""
