@@ -121,7 +121,14 @@ def broadcast_engine_key(engine, src: int = 0) -> None:
     offt = torch.tensor([off], dtype=torch.int64, device=bsk.device)
     if dist.get_backend() == "nccl":
         for t in (bsk, ksk, tv, offt):
-            dist.broadcast(t, src=src)
+            try:
+                dist.broadcast(t, src=src)  # in place, on the context's own buffer
+            except RuntimeError:
+                # a transport that insists on memory from torch's allocator: one device-side staging copy
+                st = t.clone()
+                dist.broadcast(st, src=src)
+                if dist.get_rank() != src:
+                    t.copy_(st)
     else:  # gloo moves host memory: stage (plumbing tests on boxes with fewer GPUs than ranks)
         for t in (bsk, ksk, tv, offt):
             h = t.cpu()
