@@ -184,121 +184,12 @@ __device__ __forceinline__ void external_product_half(int half_sel, const uint32
                                  fa_re, fa_im, fb_re, fb_im);
   // The remaining rows stay a LOOP: with the body duplicated (or, at L = 2, the one-trip loop flattened)
   // the scheduler overlaps rows and spills; the trip count is hidden from it for that reason.
-#ifndef TFHE_ROW_UNROLL  // 1 = the digit rows of a half are unrolled (the scheduler may then overlap rows)
-#define TFHE_ROW_UNROLL 0
-#endif
   int rows = L;
-  if (L > 1 && !TFHE_ROW_UNROLL) asm volatile("" : "+s"(rows));
-#if TFHE_ROW_UNROLL
-#pragma unroll
-#else
+  if (L > 1) asm volatile("" : "+s"(rows));
 #pragma unroll 1
-#endif
   for (int i = 1; i < rows; ++i)
     external_product_row<L, false>(half_sel * L + i, 32 - (i + 1) * bgbit, w_lo, w_hi, bsk_rsrc, bsk_i_off, tw, tile,
                                    lane, bgbit, fa_re, fa_im, fb_re, fb_im);
-}
-
-// ---- software-pipelined forward phase (TFHE_MAC_DEFER) ------------------------------------------------
-// The multiply-accumulate of digit row r does not depend on the LDS; the forward transform of row r + 1 makes two
-// LDS round trips.  Here row r's 64 FMAs are issued INSIDE row r + 1's transposes (32 behind each), with its key
-// half-rows fetched just ahead of their use (86 % of key loads are L1 hits), so that a wave
-// covers part of its own LDS latency instead of relying on the other wave of its SIMD.  The price is the previous
-// row's spectrum staying live (32 VGPRs) across the transform.  sched_barriers pin the phases: left alone, the
-// scheduler hoists every load of the unrolled rows and spills hundreds of bytes.
-#ifndef TFHE_MAC_DEFER
-#define TFHE_MAC_DEFER 0
-#endif
-#define TFHE_FENCE() __builtin_amdgcn_sched_barrier(0)
-template <int L>
-__device__ __forceinline__ void forward_phase_pipelined(const uint32_t *acc, int k, uint32_t offset, uint32_t signmask,
-                                                        __amdgpu_buffer_rsrc_t bsk_rsrc, uint32_t bsk_i_off,
-                                                        const Twiddles &tw, double2 *tile, int lane, int bgbit,
-                                                        double (&fa_re)[8], double (&fa_im)[8], double (&fb_re)[8],
-                                                        double (&fb_im)[8]) {
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-  uint32_t w_lo[8], w_hi[8];
-  double pr[8], pi[8];  // spectrum of the previous row, waiting for its multiply-accumulate
-#pragma unroll
-  for (int r = 0; r < 2 * L; ++r) {
-    if (r == 0 || r == L) {  // decomposition words of this half: (X^k*acc - acc + offset) ^ signmask
-      const uint32_t *p = acc + (r == 0 ? 0 : kN);
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const int j = lane + 64 * m;
-        w_lo[m] = (rot_read(p, j, k) - p[j] + offset) ^ signmask;
-        w_hi[m] = (rot_read(p, j + kN2, k) - p[j + kN2] + offset) ^ signmask;
-      }
-    }
-    const int shift = 32 - ((r % L) + 1) * bgbit;
-    const uint32_t prev_off = bsk_i_off + (uint32_t)(r - 1) * (2u * kN2 * 16u);
-    f64x2 kv[8];
-    if (r > 0) {  // a-half of the previous row's key: lands during pass 1
-#pragma unroll
-      for (int s = 0; s < 8; ++s) kv[s] = ldkey(bsk_rsrc, lane_off, prev_off + (uint32_t)s * 1024u);
-    }
-    double re[8], im[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      re[m] = (double)sbfe(w_lo[m], shift, bgbit);
-      im[m] = (double)sbfe(w_hi[m], shift, bgbit);
-    }
-    fwd_pass1(re, im);
-    TFHE_FENCE();
-    wave_lds_order();
-    tpA_write(re, im, tile, lane);
-    wave_lds_order();
-    tpA_read(re, im, tile, lane);
-    TFHE_FENCE();
-    if (r > 0) {  // previous row into the a accumulator, behind transpose A
-      if (r == 1) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cmac<true>(fa_re[s], fa_im[s], pr[s], pi[s], kv[s]);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cmac<false>(fa_re[s], fa_im[s], pr[s], pi[s], kv[s]);
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s) kv[s] = ldkey(bsk_rsrc, lane_off, prev_off + (uint32_t)(kN2 * 16 + s * 1024));
-    }
-    TFHE_FENCE();
-    fwd_pass2(re, im, tw, lane);
-    TFHE_FENCE();
-    wave_lds_order();
-    tpB_write(re, im, tile, lane);
-    wave_lds_order();
-    tpB_read(re, im, tile, lane);
-    TFHE_FENCE();
-    if (r > 0) {  // ... and into the b accumulator, behind transpose B
-      if (r == 1) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cmac<true>(fb_re[s], fb_im[s], pr[s], pi[s], kv[s]);
-      } else {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cmac<false>(fb_re[s], fb_im[s], pr[s], pi[s], kv[s]);
-      }
-    }
-    TFHE_FENCE();
-    fwd_pass3(re, im, tw);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      pr[s] = re[s];
-      pi[s] = im[s];
-    }
-    TFHE_FENCE();
-  }
-  {  // the last row has nothing to hide behind
-    const uint32_t last_off = bsk_i_off + (uint32_t)(2 * L - 1) * (2u * kN2 * 16u);
-    f64x2 ka[8], kb[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) ka[s] = ldkey(bsk_rsrc, lane_off, last_off + (uint32_t)s * 1024u);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) kb[s] = ldkey(bsk_rsrc, lane_off, last_off + (uint32_t)(kN2 * 16 + s * 1024));
-#pragma unroll
-    for (int s = 0; s < 8; ++s) cmac<false>(fa_re[s], fa_im[s], pr[s], pi[s], ka[s]);
-#pragma unroll
-    for (int s = 0; s < 8; ++s) cmac<false>(fb_re[s], fb_im[s], pr[s], pi[s], kb[s]);
-  }
 }
 
 struct BlindRotateArgs {
@@ -416,10 +307,6 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
     wg_sync<1>();
     const int k = s_abar[i];
     double fa_re[8], fa_im[8], fb_re[8], fb_im[8];  // written by the first row of the a half
-#if TFHE_MAC_DEFER
-    forward_phase_pipelined<L>(acc, k, offset, signmask, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane, A.bgbit,
-                               fa_re, fa_im, fb_re, fb_im);
-#else
     // cmux: tmp = in2 - in1 = X^k*acc - acc (trgsw.rs:183-186), + decomposition offset; the a
     // half is consumed before the b half is formed, so only 16 of these are ever live
     {
@@ -445,7 +332,6 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
       external_product_half<L, false>(1, t_lo, t_hi, bsk_rsrc, (uint32_t)i * per_i_bytes, tw, tile, lane, A.bgbit,
                                       signmask, fa_re, fa_im, fb_re, fb_im);
     }
-#endif
 #if TFHE_RELOAD_I3
     {
       int z = 0;
