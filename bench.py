@@ -52,12 +52,49 @@ def parse():
     ap.add_argument("--gate", default="nand", help="gate name, or 'pbs' = LutBootstrap::bootstrap_lut (m=16, x^2 mod 16), "
                     "or 'mux' / 'mux_naive', or 'mixed' = half hom_mux + half hom_xor (BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pool-devices", default=None, help="comma-separated device list: instead of the contract run, time "
+                    "ONE process driving these devices through tfhe_hip_pool_batch_gate with host buffers (what a Rust "
+                    "caller of the pool gets, PCIe included); prints its own JSON line")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU sample (whole thread sweep)")
     return ap.parse_args()
 
 
+def pool_mode(args):
+    """One process, several devices, host buffers: the Rust caller's view of tfhe_hip_pool_*."""
+    import numpy as np
+
+    import rs_tfhe_amd as R
+
+    devices = [int(d) for d in args.pool_devices.split(",")]
+    P = R.params.PARAM_SETS[args.params]
+    gate = R.engine.GATE_IDS[args.gate]
+    sk = R.SecretKey.new(P, seed=2024)
+    pool = R.Pool(P, devices)
+    t0 = time.perf_counter()
+    pool.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+    keygen_s = time.perf_counter() - t0
+    B = args.batch * len(devices)
+    rng = np.random.default_rng(1000)
+    bits_a, bits_b = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    ca, cb = sk.encrypt_bool(bits_a, seed=11), sk.encrypt_bool(bits_b, seed=12)
+    for _ in range(args.warmup):
+        out = pool.batch_gate(gate, ca, cb)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = pool.batch_gate(gate, ca, cb)
+    elapsed = time.perf_counter() - t0
+    ok = bool(np.array_equal(sk.decrypt_bool(out), GATE_TRUTH[args.gate](bits_a, bits_b)))
+    print(json.dumps({
+        "metric": f"gate-bootstraps/sec (hom_{args.gate}, {args.params}), single process, tfhe_hip_pool over host buffers",
+        "value": round(B * args.steps / elapsed, 1), "unit": "bootstraps/s", "devices": devices, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "batch_total": B,
+        "pcie_inclusive": True, "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
+
+
 def main():
     args = parse()
+    if args.pool_devices:
+        return pool_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start it as a child (never exec after touching the GPU)
@@ -102,9 +139,12 @@ def main():
     # other ranks' GPUs; ciphertexts: fresh encryptions of uniform bits / messages
     t0 = time.time()
     sk = R.SecretKey.new(P, seed=2024)  # explicit seeds: a benchmark wants reproducible inputs (never a real key)
-    eng = R.Engine(P, local_rank)
+    # the handle a Rust caller binds (tfhe_hip_pool_*): one member per rank here, because the
+    # driver's contract is one process per GPU; the timed calls go to the member context's *_dev entry points
+    pool = R.Pool(P, [local_rank])
+    eng = R.Engine.from_pool(pool, 0)
     if world == 1 or rank == 0:
-        eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+        pool.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
     if world > 1:  # ONE key, generated on rank 0 and replicated device to device (RCCL broadcast, engine layouts)
         R.distributed.broadcast_engine_key(eng, src=0)
     rng = np.random.default_rng(1000 + rank)

@@ -54,16 +54,35 @@ class Engine:
             msg = self._lib.tfhe_hip_last_error(None)
             raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._ctx = ctx
+        self._owner = None  # a Pool when the context is borrowed from one (tfhe_hip_pool_ctx): never destroyed here
         self._key = None  # the CloudKey object currently loaded (held, so identity cannot be recycled)
         # held by bootstrap.keyed_engine() across "make this key current" + the launch that needs it
         self.lock = threading.RLock()
         self._last_use = 0
 
+    @classmethod
+    def from_pool(cls, pool: "Pool", member: int) -> "Engine":
+        """The member context of a pool as an Engine (for the device-resident `*_dev` entry points).  The pool keeps
+        ownership; do not run pool batch calls while this engine has work in flight (include/tfhe_hip.h)."""
+        ctx = pool._lib.tfhe_hip_pool_ctx(pool._h, int(member))
+        if not ctx:
+            raise ValueError("no such pool member")
+        self = cls.__new__(cls)
+        self.params, self.device, self._lib = pool.params, pool.devices[member], pool._lib
+        self._ctx = C.c_void_p(ctx)
+        self._owner = pool
+        self._key = ("pool", object())
+        self.lock = threading.RLock()
+        self._last_use = 0
+        return self
+
     # -- lifetime -------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_ctx", None):
-            self._lib.tfhe_hip_ctx_destroy(self._ctx)
+            if getattr(self, "_owner", None) is None:
+                self._lib.tfhe_hip_ctx_destroy(self._ctx)
             self._ctx = None
+            self._owner = None
 
     def __del__(self):
         try:

@@ -900,6 +900,19 @@ def test_pool_two_contexts_bit_exact_and_order_preserving(O, eng128, keys128):
     assert np.array_equal(sk.decrypt_bool(pool.batch_gate(O.GATE_NAND, ca, ca)), ~A)
     with pytest.raises(R._capi.TfheHipError):
         pool.batch_gate(99, ca, ca)
+    # a member context borrowed for the device-resident entry points (what bench.py times)
+    import torch
+
+    member = R.Engine.from_pool(pool, 1)
+    ta = torch.from_numpy(ca.view(np.int32)).to("cuda:0")
+    to = torch.empty_like(ta)
+    member.batch_gate_dev(O.GATE_NAND, ta, ta, to)
+    torch.cuda.synchronize()
+    assert np.array_equal(to.cpu().numpy().view(np.uint32), pool.batch_gate(O.GATE_NAND, ca, ca))
+    member.close()  # borrowed: the pool still owns the context
+    assert np.array_equal(sk.decrypt_bool(pool.batch_gate(O.GATE_NAND, ca, ca)), ~A)
+    with pytest.raises(ValueError):
+        R.Engine.from_pool(pool, 2)
     pool.close()
     with pytest.raises(R._capi.TfheHipError):
         R.Pool(P, [0, 4096])  # no such device: create fails as a whole
