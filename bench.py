@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--params", default="SECURITY_128_BIT")
     ap.add_argument("--gate", default="nand", help="gate name, or 'pbs' = LutBootstrap::bootstrap_lut (m=16, x^2 mod 16), "
                     "or 'mux' / 'mux_naive', or 'mixed' = half hom_mux + half hom_xor (BASELINE configs[4])")
+    ap.add_argument("--modulus", type=int, default=16, help="message modulus of the 'pbs' workload (16 fits SECURITY_UINT4; "
+                    "UINT1 / UINT2 / UINT3 take 2 / 4 / 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pool-devices", default=None, help="comma-separated device list: instead of the contract run, time "
                     "ONE process driving these devices through tfhe_hip_pool_batch_gate with host buffers (what a Rust "
@@ -151,15 +153,15 @@ def main():
     bits_a = rng.integers(0, 2, B).astype(bool)
     bits_b = rng.integers(0, 2, B).astype(bool)
     bits_c = rng.integers(0, 2, B).astype(bool)
-    msgs = rng.integers(0, 16, B)
+    msgs = rng.integers(0, args.modulus, B)
     if args.gate == "pbs":
-        ca = sk.encrypt_lwe_message(msgs, 16, seed=11 + 3 * rank)
+        ca = sk.encrypt_lwe_message(msgs, args.modulus, seed=11 + 3 * rank)
         cb = ca
     else:
         ca = sk.encrypt_bool(bits_a, seed=11 + 3 * rank)
         cb = sk.encrypt_bool(bits_b, seed=12 + 3 * rank)
     cc = sk.encrypt_bool(bits_c, seed=13 + 3 * rank) if args.gate.startswith("mux") or args.gate == "mixed" else None
-    lut = R.lut.Generator(16).generate_lookup_table(lambda x: (x * x) % 16) if args.gate == "pbs" else None
+    lut = R.lut.Generator(args.modulus).generate_lookup_table(lambda x: (x * x) % args.modulus) if args.gate == "pbs" else None
     setup_s = time.time() - t0
 
     ta = torch.from_numpy(ca.view(np.int32)).to(dev)
@@ -244,7 +246,7 @@ def main():
     # ---- sanity: decrypt the shard (integer, host) ----
     out = to.cpu().numpy().view(np.uint32)
     if args.gate == "pbs":
-        decrypt_ok = bool(np.array_equal(sk.decrypt_lwe_message(out, 16), (msgs ** 2) % 16))
+        decrypt_ok = bool(np.array_equal(sk.decrypt_lwe_message(out, args.modulus), (msgs ** 2) % args.modulus))
     elif args.gate == "mux":
         decrypt_ok = None  # Gates::mux is the reference formula: no decrypt claim
     elif args.gate == "mixed":  # claim only the xor half (the mux half is the Q5 formula)
