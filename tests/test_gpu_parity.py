@@ -630,6 +630,45 @@ def test_bad_gate_code_on_the_device_is_reported(O, eng128, keys128):
     eng128.synchronize()  # a clean launch leaves no flag behind
 
 
+def test_two_threads_two_keys_through_the_gates_api():
+    """`Gates` / `gates.batch_*` take `cloud_key` per call like the reference (`&CloudKey`, Send + Sync strategies,
+    bootstrap/mod.rs:23): two threads alternating between two keys must each compute under their own key.  The
+    mirrors choose the key and launch in one critical section and keep one resident context per key
+    (bootstrap.keyed_engine); a shared context whose key is "ensured" and then used in two steps fails this."""
+    import threading
+
+    import rs_tfhe_amd as R
+
+    P = R.params.SECURITY_128_BIT
+    sks = [R.SecretKey.new(P, seed=5100 + i) for i in range(2)]
+    cks = [R.CloudKey.new(sk, seed=5200 + i) for i, sk in enumerate(sks)]
+    bad, errs = [0, 0], []
+
+    def worker(t):
+        try:
+            sk, ck = sks[t], cks[t]
+            rng = np.random.default_rng(5300 + t)
+            g = R.Gates()
+            for it in range(5):
+                A, B = rng.integers(0, 2, 6).astype(bool), rng.integers(0, 2, 6).astype(bool)
+                ca, cb = sk.encrypt_bool(A, seed=int(rng.integers(1 << 30))), sk.encrypt_bool(B, seed=int(rng.integers(1 << 30)))
+                bad[t] += int((sk.decrypt_bool(R.gates.batch_nand(ca, cb, ck)) != ~(A & B)).sum())
+                bad[t] += int(bool(sk.decrypt_bool(g.xor(ca[0], cb[0], ck))[0]) != bool(A[0] ^ B[0]))
+                bad[t] += int((sk.decrypt_bool(g.mux_naive(ca, cb, ca, ck)) != np.where(A, B, A)).sum())
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    assert bad == [0, 0], bad
+    pool = R.bootstrap._engines[(P, 0)]
+    assert sum(e._key is cks[0] for e in pool) == 1 and sum(e._key is cks[1] for e in pool) == 1  # both stayed resident
+
+
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
     """Batches <= #CUs go through the 2l-waves-per-ciphertext latency kernel, larger ones through the
     one-wave-per-ciphertext batch kernel: both must give the oracle's bits, for every output form."""
