@@ -286,7 +286,14 @@ def main():
     traffic = pm.get("blind_rotate", {}).get("hbm_bytes_per_launch")
     # Instruction mix of one CMUX step of the build being timed (rs-tfhe_amd/kernel_isa.json, written by `make`
     # from the compiler's gfx950 assembly; cross-check: SQ_INSTS_VALU per launch / (batch * n) in profiles/).
-    isa = json.load(open(os.path.join(ROOT, "rs-tfhe_amd", "kernel_isa.json")))[f"l{P.l}"]
+    try:
+        isa = json.load(open(os.path.join(ROOT, "rs-tfhe_amd", "kernel_isa.json")))[f"l{P.l}"]
+        isa_source = "rs-tfhe_amd/kernel_isa.json (this build)"
+    except (OSError, KeyError, ValueError):  # library built without the Makefile's ISA step: the round-2 counts
+        isa = {1: {"f64_flop_per_lane": 1946, "valu": 1335, "f64_fma": 876, "f64_add": 120, "f64_mul": 74, "f64_other": 32},
+               2: {"f64_flop_per_lane": 3066, "valu": 1962, "f64_fma": 1436, "f64_add": 120, "f64_mul": 74, "f64_other": 64},
+               3: {"f64_flop_per_lane": 4186, "valu": 2588, "f64_fma": 1996, "f64_add": 120, "f64_mul": 74, "f64_other": 96}}[P.l]
+        isa_source = "fallback table (round-2 build)"
     wave_steps_per_s = P.n * per_launch / (br_ms * 1e-3) if br_ms > 0 else 0.0  # CMUX steps of one wave, whole chip
     tflops = wave_steps_per_s * 64 * isa["f64_flop_per_lane"] / 1e12
     shader_mhz = clk["shader_mhz"] or None
@@ -304,6 +311,7 @@ def main():
         "avg_launch_ms": round(br_ms, 3),
         "f64_flop_per_lane_per_cmux_step": isa["f64_flop_per_lane"],
         "valu_instr_per_cmux_step": isa["valu"],
+        "instruction_mix_source": isa_source,
         "shader_mhz": round(shader_mhz, 1) if shader_mhz else None,
         "board_power_w": power_w,
         "board_power_cap_w": power_cap_w,
