@@ -138,7 +138,7 @@ __device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
 }
 
 constexpr int kKsRingSlots = 3;  // groups resident in LDS (measured: 2 / 4 / 5 slots 56 / 40 / 46 ms vs 23 ms)
-constexpr int kKsStage = 64;     // coefficients whose a_bar words are staged in LDS at a time
+constexpr int kKsStage = 64;     // coefficients whose a_bar words are staged in LDS at a time (32 / 16: 24.3 / 24.2 vs 24.1 ms)
 constexpr uint32_t kKsWaveBytes = 1024;   // one DMA instruction: 64 lanes x 16 B = this wave's columns of one row
 
 // LDS per workgroup of `nw` waves: ring[NS][zero row, 3 rows][nw KiB] | a_bar staging.  Each wave
