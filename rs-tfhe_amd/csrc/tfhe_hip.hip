@@ -250,11 +250,11 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   }
   dim3 block(64 * kBrWaves);
   size_t lds = br_lds_bytes(ctx);
-  // Launch in rounds of exactly the resident set: every workgroup of a round starts
-  // step 0 together and streams the bootstrapping key in near lock-step, so each key
-  // row is pulled from HBM / Infinity Cache into an XCD's L2 once per round instead of
-  // once per workgroup.  (One launch of the whole batch lets rounds drift apart and
-  // the 4 MiB L2s thrash: measured 1.5 TB fabric reads per 65,536 bootstraps.)
+  // Default: ONE launch of the whole batch.  The four waves of a workgroup meet at a barrier every CMUX step
+  // (blind_rotate.hpp), which keeps the resident workgroups streaming the key in near lock-step on its own:
+  // L1 86 % / L2 97 % hits, 36 GB of HBM-side traffic per 65,536 bootstraps.  TFHE_HIP_BR_CHUNK splits the
+  // batch into launches of N ciphertexts (-1: the resident set) -- the round-1 remedy for free-running
+  // one-wave workgroups, whose rounds drifted apart until the 4 MiB L2s thrashed; kept for experiments.
   size_t chunk = count;
   if (ctx->br_chunk > 0) chunk = (size_t)ctx->br_chunk;
   if (ctx->br_chunk < 0) {
