@@ -24,6 +24,23 @@ def test_header_symbols_exported():
     assert _capi.lib().tfhe_hip_name() == b"hip-gfx950"
 
 
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/tfhe_hip.h must compile as C99 (no C++-isms), which is what a
+    cgo / bindgen / ctypes consumer sees."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("gcc not available")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "tfhe_hip.h"\nint main(void) { tfhe_hip_pool *p = 0; tfhe_hip_ctx *c = 0; (void)p; (void)c; '
+                   'return sizeof(tfhe_hip_kernel_times) + sizeof(tfhe_hip_clock_sample) + sizeof(tfhe_hip_params) > 0 ? 0 : 1; }\n')
+    r = subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_no_cpu_fallback_in_product_package():
     """The product path must not import or call anything under oracle/."""
     pkg = os.path.join(ROOT, "rs-tfhe_amd")
