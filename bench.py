@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--pool-devices", default=None, help="comma-separated device list: instead of the contract run, time "
                     "ONE process driving these devices through tfhe_hip_pool_batch_gate with host buffers (what a Rust "
                     "caller of the pool gets, PCIe included); prints its own JSON line")
+    ap.add_argument("--pinned", action="store_true", help="with --pool-devices: operands in pinned host memory "
+                    "(tfhe_hip_host_alloc): read and written in place over PCIe, no staging copies")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU sample (whole thread sweep)")
     return ap.parse_args()
 
@@ -79,18 +81,22 @@ def pool_mode(args):
     rng = np.random.default_rng(1000)
     bits_a, bits_b = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     ca, cb = sk.encrypt_bool(bits_a, seed=11), sk.encrypt_bool(bits_b, seed=12)
+    out = None
+    if args.pinned:
+        ca, cb, out = R.engine.pinned_copy(ca), R.engine.pinned_copy(cb), R.engine.pinned_empty(ca.shape)
     for _ in range(args.warmup):
-        out = pool.batch_gate(gate, ca, cb)
+        out = pool.batch_gate(gate, ca, cb, out=out)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = pool.batch_gate(gate, ca, cb)
+        out = pool.batch_gate(gate, ca, cb, out=out)
     elapsed = time.perf_counter() - t0
     ok = bool(np.array_equal(sk.decrypt_bool(out), GATE_TRUTH[args.gate](bits_a, bits_b)))
     print(json.dumps({
         "metric": f"gate-bootstraps/sec (hom_{args.gate}, {args.params}), single process, tfhe_hip_pool over host buffers",
         "value": round(B * args.steps / elapsed, 1), "unit": "bootstraps/s", "devices": devices, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "batch_total": B,
-        "pcie_inclusive": True, "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
+        "pcie_inclusive": True, "host_memory": "pinned (zero-copy)" if args.pinned else "pageable (staged)",
+        "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
 
 
 def main():

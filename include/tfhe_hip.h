@@ -154,6 +154,15 @@ int tfhe_hip_cloud_key_buffers(tfhe_hip_ctx *ctx, void **bsk, size_t *bsk_bytes,
                                void **testvec, size_t *testvec_bytes, uint32_t *decomp_offset);
 int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset);
 
+/* Pinned host buffers.  The host entry points below take ordinary (pageable) memory and stage it through the
+ * device around the kernels: 3 x 184 MB for a 65,536-ciphertext gate batch, about 7 % of the call.  When EVERY
+ * ciphertext operand of a call (inputs and output) is pinned host memory -- allocated here, or the caller's own
+ * buffers registered with hipHostRegister -- the kernels read and write it in place over PCIe (each ciphertext is
+ * read once in the blind rotation's prologue and written once by the key switch) and the call runs at the
+ * device-resident rate.  Nothing else changes: same functions, same arguments, same results. */
+int tfhe_hip_host_alloc(size_t bytes, void **out);
+void tfhe_hip_host_free(void *p);
+
 /* ---- the hot path, batched --------------------------------------------- */
 
 /* Replaces: gates::batch_{nand,and,or,xor,nor,xnor}[_with_railgun]

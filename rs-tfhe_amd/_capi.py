@@ -62,6 +62,8 @@ SIGNATURES = {
     "tfhe_hip_cloud_key_buffers": (C.c_int, [_CTX, C.POINTER(_P), C.POINTER(_SZ), C.POINTER(_P), C.POINTER(_SZ),
                                              C.POINTER(_P), C.POINTER(_SZ), C.POINTER(C.c_uint32)]),
     "tfhe_hip_adopt_cloud_key": (C.c_int, [_CTX, C.c_uint32]),
+    "tfhe_hip_host_alloc": (C.c_int, [_SZ, C.POINTER(_P)]),
+    "tfhe_hip_host_free": (None, [_P]),
     "tfhe_hip_export_cloud_key": (C.c_int, [_CTX, _P, _P, C.POINTER(C.c_uint32), _P]),
     "tfhe_hip_batch_gate": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_gate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),

@@ -443,6 +443,28 @@ int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
   return TFHE_HIP_OK;
 }
 
+// Zero-copy for pinned host buffers: memory from tfhe_hip_host_alloc (hipHostMalloc) or registered with
+// hipHostRegister is addressable by the GPU, so the host entry points hand such buffers to the kernels as they
+// are -- each ciphertext is read once in the blind rotation's prologue and written once by the key switch, and
+// those PCIe transactions spread over the whole launch instead of three staging copies around it.
+// Returns the device view of `p`, or nullptr when `p` is ordinary pageable memory.
+template <class T>
+T *pinned_view(T *p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, (const void *)p) != hipSuccess) {
+    (void)hipGetLastError();  // pageable memory is "invalid value" to the runtime: not an error here
+    return nullptr;
+  }
+  if (at.type != hipMemoryTypeHost) return nullptr;
+  void *d = nullptr;
+  if (hipHostGetDevicePointer(&d, (void *)p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return (T *)d;
+}
+
 }  // namespace
 
 // =============================================================================
@@ -862,6 +884,15 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
   if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
   if (!a || !out || (gp.cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  {  // all operands pinned: no staging (see pinned_view)
+    const uint32_t *da = pinned_view(a), *db = gp.cb ? pinned_view(b) : nullptr;
+    uint32_t *dout = pinned_view(out);
+    if (da && dout && (!gp.cb || db)) {
+      CHK(gate_dev(ctx, gate, da, db, dout, count, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return TFHE_HIP_OK;
+    }
+  }
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   if (gp.cb) CHK(to_dev(ctx, ctx->h_b, b, bytes));
   CHK(ensure(ctx, ctx->h_out, bytes));
@@ -879,9 +910,18 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
   for (size_t i = 0; i < count; ++i)
     if (gates[i] > TFHE_HIP_COPY) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_idx, gates, count));  // one byte per ciphertext: always staged
+  {
+    const uint32_t *da = pinned_view(a), *db = pinned_view(b);
+    uint32_t *dout = pinned_view(out);
+    if (da && db && dout) {
+      CHK(gates_mixed_dev(ctx, (const uint8_t *)ctx->h_idx.p, da, db, dout, count, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return TFHE_HIP_OK;
+    }
+  }
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
-  CHK(to_dev(ctx, ctx->h_idx, gates, count));
   CHK(ensure(ctx, ctx->h_out, bytes));
   CHK(gates_mixed_dev(ctx, (const uint8_t *)ctx->h_idx.p, (uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_b.p,
                       (uint32_t *)ctx->h_out.p, count, ctx->stream));
@@ -915,12 +955,24 @@ int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32
   if (count == 0) return TFHE_HIP_OK;
   if (!in || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
-  CHK(to_dev(ctx, ctx->h_a, in, bytes));
   const uint32_t *d_tv = nullptr;
   if (testvec) {
-    CHK(to_dev(ctx, ctx->h_tv, testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4));
-    d_tv = (const uint32_t *)ctx->h_tv.p;
+    d_tv = pinned_view(testvec);
+    if (!d_tv) {
+      CHK(to_dev(ctx, ctx->h_tv, testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4));
+      d_tv = (const uint32_t *)ctx->h_tv.p;
+    }
   }
+  {
+    const uint32_t *din = pinned_view(in);
+    uint32_t *dout = pinned_view(out);
+    if (din && dout) {
+      CHK(bootstrap_dev(ctx, din, d_tv, per_ct, keyswitch, dout, count, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return TFHE_HIP_OK;
+    }
+  }
+  CHK(to_dev(ctx, ctx->h_a, in, bytes));
   CHK(ensure(ctx, ctx->h_out, bytes));
   CHK(bootstrap_dev(ctx, (uint32_t *)ctx->h_a.p, d_tv, per_ct, keyswitch, (uint32_t *)ctx->h_out.p, count, ctx->stream));
   return to_host(ctx, out, ctx->h_out, bytes);
@@ -994,6 +1046,15 @@ int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const ui
   if (count == 0) return TFHE_HIP_OK;
   if (!a || !b || !c || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  {
+    const uint32_t *da = pinned_view(a), *db = pinned_view(b), *dc = pinned_view(c);
+    uint32_t *dout = pinned_view(out);
+    if (da && db && dc && dout) {
+      CHK(mux_dev(ctx, naive, da, db, dc, dout, count, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return TFHE_HIP_OK;
+    }
+  }
   CHK(to_dev(ctx, ctx->h_a, a, bytes));
   CHK(to_dev(ctx, ctx->h_b, b, bytes));
   CHK(to_dev(ctx, ctx->h_c, c, bytes));
@@ -1146,6 +1207,23 @@ int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out) {
   out->rtc_mhz = ctx->rtc_khz / 1000.0;
   out->shader_mhz = h[1] ? (double)h[0] / (double)h[1] * out->rtc_mhz : 0.0;
   return TFHE_HIP_OK;
+}
+
+int tfhe_hip_host_alloc(size_t bytes, void **out) {
+  if (!out) return TFHE_HIP_EINVAL;
+  *out = nullptr;
+  if (bytes == 0) return TFHE_HIP_OK;
+  const hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+    *out = nullptr;
+    return e == hipErrorOutOfMemory ? TFHE_HIP_ENOMEM : TFHE_HIP_EHIP;
+  }
+  return TFHE_HIP_OK;
+}
+
+void tfhe_hip_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int tfhe_hip_synchronize(tfhe_hip_ctx *ctx) {

@@ -39,6 +39,40 @@ def _tptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+def pinned_empty(shape, dtype=np.uint32) -> np.ndarray:
+    """A numpy array in pinned host memory (`tfhe_hip_host_alloc`).  The host entry points read and write such
+    arrays in place over PCIe -- no staging copies -- when every ciphertext operand of the call is pinned."""
+    lib = _capi.lib()
+    shape = (shape,) if np.isscalar(shape) else tuple(shape)
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = C.c_void_p()
+    rc = lib.tfhe_hip_host_alloc(max(nbytes, 1), C.byref(p))
+    if rc != _capi.OK:
+        msg = lib.tfhe_hip_last_error(None)
+        raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(p.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    import weakref
+
+    weakref.finalize(buf, lib.tfhe_hip_host_free, C.c_void_p(p.value))  # freed when the last view is gone
+    return arr
+
+
+def _out_like(a: np.ndarray, out) -> np.ndarray:
+    if out is None:
+        return np.empty_like(a)
+    if out.dtype != np.uint32 or out.shape != a.shape or not out.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous uint32 array of the operands' shape")
+    return out
+
+
+def pinned_copy(a) -> np.ndarray:
+    a = np.ascontiguousarray(a)
+    out = pinned_empty(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
 class Engine:
     """Owns a tfhe_hip_ctx.  Host arrays are numpy uint32; *_dev methods take
     torch CUDA tensors (int32 storage of the u32 words) and only enqueue work."""
@@ -188,12 +222,14 @@ class Engine:
         a = _u32(a)
         return a.reshape(-1, self.params.n + 1)
 
-    def batch_gate(self, gate: int, a, b=None) -> np.ndarray:
+    def batch_gate(self, gate: int, a, b=None, out=None) -> np.ndarray:
+        """`out`: optional preallocated [count][n+1] uint32 result array -- pass pinned arrays (`pinned_empty`) for
+        a, b and out and the call runs without staging copies."""
         a = self._cts(a)
         bb = self._cts(b) if b is not None else None
         if bb is not None and bb.shape != a.shape:
             raise ValueError("operand batches differ in shape")
-        out = np.empty_like(a)
+        out = _out_like(a, out)
         self._chk(self._lib.tfhe_hip_batch_gate(self._ctx, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
         return out
 
@@ -514,12 +550,12 @@ class Pool:
     def _cts(self, a) -> np.ndarray:
         return _u32(a).reshape(-1, self.params.n + 1)
 
-    def batch_gate(self, gate: int, a, b=None) -> np.ndarray:
+    def batch_gate(self, gate: int, a, b=None, out=None) -> np.ndarray:
         a = self._cts(a)
         bb = self._cts(b) if b is not None else None
         if bb is not None and bb.shape != a.shape:
             raise ValueError("operand batches differ in shape")
-        out = np.empty_like(a)
+        out = _out_like(a, out)
         self._chk(self._lib.tfhe_hip_pool_batch_gate(self._h, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
         return out
 

@@ -669,6 +669,54 @@ def test_two_threads_two_keys_through_the_gates_api():
     assert sum(e._key is cks[0] for e in pool) == 1 and sum(e._key is cks[1] for e in pool) == 1  # both stayed resident
 
 
+def test_pinned_host_buffers_run_in_place(O, eng128, keys128):
+    """tfhe_hip_host_alloc: when every ciphertext operand of a host-API call is pinned memory the kernels read and
+    write it in place (no staging); results must be the same words as through pageable arrays, for every entry
+    point with the fast path, at a small (latency kernels) and a large (batch kernels) count, and through the pool."""
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd.engine import pinned_copy, pinned_empty
+
+    sk, ck = keys128
+    rng = np.random.default_rng(5400)
+    for count in (3, 1500):
+        A, B, Cc = (rng.integers(0, 2, count).astype(bool) for _ in range(3))
+        ca, cb, cc = sk.encrypt_bool(A, 5401), sk.encrypt_bool(B, 5402), sk.encrypt_bool(Cc, 5403)
+        pa, pb, pc = pinned_copy(ca), pinned_copy(cb), pinned_copy(cc)
+        po = pinned_empty(ca.shape)
+        po[...] = 0xDEADBEEF
+        want = eng128.batch_gate(O.GATE_NAND, ca, cb)
+        got = eng128.batch_gate(O.GATE_NAND, pa, pb, out=po)
+        assert got is po and np.array_equal(po, want) and np.array_equal(sk.decrypt_bool(po), ~(A & B))
+        assert np.array_equal(pa, ca) and np.array_equal(pb, cb)  # inputs untouched
+        # mixed operands (one pageable): falls back to staging, same words
+        assert np.array_equal(eng128.batch_gate(O.GATE_NAND, pa, cb, out=pinned_empty(ca.shape)), want)
+        lib, ctx = eng128._lib, eng128._ctx
+        import ctypes as C
+
+        def p(x):
+            return x.ctypes.data_as(C.c_void_p)
+
+        po[...] = 0
+        codes = rng.integers(0, 11, count).astype(np.uint8)
+        assert lib.tfhe_hip_batch_gates_mixed(ctx, p(codes), p(pa), p(pb), p(po), count) == 0
+        assert np.array_equal(po, eng128.batch_gates_mixed(codes, ca, cb))
+        po[...] = 0
+        assert lib.tfhe_hip_batch_bootstrap(ctx, p(pa), None, 0, 1, p(po), count) == 0
+        assert np.array_equal(po, eng128.batch_bootstrap(ca))
+        tv = pinned_copy(rng.integers(0, 2**32, (count, 2, N), dtype=np.uint64).astype(np.uint32))
+        assert lib.tfhe_hip_batch_bootstrap(ctx, p(pa), p(tv), 1, 0, p(po), count) == 0
+        assert np.array_equal(po, eng128.batch_bootstrap(ca, np.array(tv), keyswitch=False))
+        for naive in (1, 0):
+            po[...] = 0
+            assert lib.tfhe_hip_batch_mux(ctx, naive, p(pa), p(pb), p(pc), p(po), count) == 0
+            assert np.array_equal(po, eng128.batch_mux(ca, cb, cc, naive=bool(naive)))
+    pool = R.Pool(eng128.params, [0, 0])
+    pool.load_cloud_key(_cloud_key(ck))
+    po[...] = 0
+    assert np.array_equal(pool.batch_gate(O.GATE_NAND, pa, pb, out=po), want)  # shards are interior pointers of pinned arrays
+    pool.close()
+
+
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
     """Batches <= #CUs go through the 2l-waves-per-ciphertext latency kernel, larger ones through the
     one-wave-per-ciphertext batch kernel: both must give the oracle's bits, for every output form."""
