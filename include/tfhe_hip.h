@@ -325,8 +325,10 @@ int tfhe_hip_synchronize(tfhe_hip_ctx *ctx);
  * order-preserving, embarrassingly parallel map over the ciphertexts of a slice under one shared read-only
  * &CloudKey.  A pool is that map over devices: one context per entry of `devices` (an entry may repeat: two
  * contexts on one GPU), the cloud key generated / uploaded once on the first device and replicated device to
- * device in the engine layouts, the batch split contiguously (shard r of k = tfhe_hip_pool_shard), one host
- * thread per shard, results written into the caller's output slice in input order.  No collective and no
+ * device in the engine layouts, the batch split contiguously over the first k = min(ndev, ceil(count / 256))
+ * members (shard r of k = tfhe_hip_pool_shard; batches under 256 ciphertexts per device are not cut thinner: a
+ * device runs that many in the time of one), one host thread per shard, results written into the caller's output
+ * slice in input order.  No collective and no
  * exchange between devices on the data path.  Pool calls are serialised per pool; a member context borrowed
  * with tfhe_hip_pool_ctx() (for the *_dev entry points) must not be used while a pool call runs. */
 typedef struct tfhe_hip_pool tfhe_hip_pool;

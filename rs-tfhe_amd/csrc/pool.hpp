@@ -63,9 +63,17 @@ int replicate_key(tfhe_hip_pool *p) {
 }
 
 // run(ctx, lo, hi) on every non-empty shard, shard 0 on the calling thread; first failure wins
+// Members a batch of `count` is spread over: one device runs up to 256 ciphertexts in the time of one (the
+// latency kernels give every ciphertext its own workgroup), so smaller batches are not cut thinner than that.
+inline int pool_world_for(const tfhe_hip_pool *p, size_t count) {
+  const size_t want = (count + 255) / 256;
+  const size_t have = p->ctxs.size();
+  return (int)(want < 1 ? 1 : (want < have ? want : have));
+}
+
 template <class F>
 int pool_map(tfhe_hip_pool *p, size_t count, F &&run) {
-  const int world = (int)p->ctxs.size();
+  const int world = pool_world_for(p, count);
   std::vector<int> rc((size_t)world, TFHE_HIP_OK);
   std::vector<std::thread> th;
   for (int r = 1; r < world; ++r) {

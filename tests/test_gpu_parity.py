@@ -962,7 +962,7 @@ def test_pool_two_contexts_bit_exact_and_order_preserving(O, eng128, keys128):
     assert np.array_equal(k1.bootstrapping_key, k0.bootstrapping_key) and np.array_equal(k1.key_switching_key, k0.key_switching_key)
     assert np.array_equal(k1.key_switching_key, pk.key_switching_key) and k1.decomposition_offset == pk.decomposition_offset
     rng = np.random.default_rng(77)
-    for count in (1, 2, 5, 37, 700):
+    for count in (1, 5, 300, 513, 701):  # <= 256: one member; 300 -> 150 + 150; 513 -> 257 + 256; 701 -> 351 + 350
         A, B, Cc = (rng.integers(0, 2, count).astype(bool) for _ in range(3))
         ca, cb, cc = sk.encrypt_bool(A, 100 + count), sk.encrypt_bool(B, 200 + count), sk.encrypt_bool(Cc, 300 + count)
         got = pool.batch_gate(O.GATE_NAND, ca, cb)
