@@ -333,6 +333,12 @@ def main():
             "whole_path_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
         },
         "physical_hbm_frac": round(traffic / (br_ms * 1e-3) / 8e12, 4) if traffic and br_ms > 0 else None,
+        # flat copies of what the sub-objects hold, for parsers that keep only scalars
+        "algorithmic_hbm_GBps": round(achieved, 1),
+        "algorithmic_hbm_ratio_to_peak": round(achieved / 8000.0, 4),
+        "whole_path_algorithmic_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
+        "key_switch_avg_launch_ms": round(ks_ms, 3),
+        "key_switch_issue_frac": pm.get("key_switch", {}).get("issue_frac"),
         "key_switch": {
             "avg_launch_ms": round(ks_ms, 3),
             "bound": "valu+salu issue",
