@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
   for (int i = 0; i < L; ++i) signmask |= 1u << (32 - i * A.bgbit - 1);
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
-    wg_sync<1>();
+    wg_sync<1>();  // (a barrier only every 2nd / 4th / 16th step: 722 / 713 / 698 M cycles and 331.9 / 332.1 / 333.4 ms vs 331.7)
     const int k = s_abar[i];
     double fa_re[8], fa_im[8], fb_re[8], fb_im[8];  // written by the first row of the a half
     // cmux: tmp = in2 - in1 = X^k*acc - acc (trgsw.rs:183-186), + decomposition offset; the a
