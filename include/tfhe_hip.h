@@ -336,6 +336,7 @@ typedef struct tfhe_hip_pool tfhe_hip_pool;
 int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int ndev, tfhe_hip_pool **out);
 void tfhe_hip_pool_destroy(tfhe_hip_pool *pool);
 int tfhe_hip_pool_size(const tfhe_hip_pool *pool);
+/* A member context, BORROWED: valid until tfhe_hip_pool_destroy, never to be passed to tfhe_hip_ctx_destroy. */
 tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *pool, int member);
 /* Text of the last failed pool call ("device D: ..."), or of the last failed create when pool == NULL. */
 const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *pool);

@@ -80,8 +80,9 @@ __device__ __forceinline__ uint32_t gaussian_torus(double mu, double g) { return
 // (tlwe.rs:37-53): a uniform, b = <a, s0> + gaussian_f64(p).
 __global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ key_lv0, const uint32_t *__restrict__ key_lv1,
                                                   uint32_t *__restrict__ ksk_eng, int n, int basebit, int t,
-                                                  double alpha, ChaChaKey key) {
+                                                  double alpha, const ChaChaKey *__restrict__ key_p) {
   __shared__ uint32_t s_part[4];
+  const ChaChaKey key = *key_p;  // the generator key lives in a device buffer the host wipes after the launch
   const uint32_t row = blockIdx.x;  // base*t*i + base*j + k
   const int base = 1 << basebit;
   const int k = row % base, j = (row / base) % t, i = row / (base * t);
@@ -148,7 +149,8 @@ __global__ __launch_bounds__(64) void k_key_spectrum(const uint32_t *__restrict_
 template <int L>
 __global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key_lv0, const double2 *__restrict__ s1_spec,
                                                  const double2 *__restrict__ twt, double2 *__restrict__ bsk_eng,
-                                                 int bgbit, double alpha, ChaChaKey key) {
+                                                 int bgbit, double alpha, const ChaChaKey *__restrict__ key_p) {
+  const ChaChaKey key = *key_p;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
   const int lane = threadIdx.x;

@@ -8,6 +8,7 @@
 // shard (each thread makes its shard's device current; the HIP current device is per thread), results
 // written in place into the caller's output slice.  No collective and no exchange on the data path.
 #pragma once
+#include <system_error>
 #include <thread>
 
 struct tfhe_hip_pool {
@@ -79,7 +80,12 @@ int pool_map(tfhe_hip_pool *p, size_t count, F &&run) {
   for (int r = 1; r < world; ++r) {
     size_t lo, hi;
     pool_shard(count, r, world, lo, hi);
-    if (hi > lo) th.emplace_back([&, r, lo, hi] { rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi); });
+    if (hi <= lo) continue;
+    try {
+      th.emplace_back([&, r, lo, hi] { rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi); });
+    } catch (const std::system_error &) {  // no thread to be had: this shard runs on the calling thread
+      rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi);
+    }
   }
   {
     size_t lo, hi;

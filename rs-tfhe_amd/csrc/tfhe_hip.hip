@@ -646,15 +646,19 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   double2 *d_spec = (double2 *)ctx->h_c.p;
   hipLaunchKernelGGL(k_key_spectrum, dim3(1), dim3(64), kStageLdsBytes, ctx->stream, d_k1, ctx->d_tw, d_spec);
   HIPCHK(ctx, hipGetLastError());
+  // the generator key travels in a device buffer (not in kernel-argument memory) and is wiped with the other secrets
+  CHK(ensure(ctx, ctx->h_idx, sizeof(ChaChaKey)));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->h_idx.p, &rk, sizeof(ChaChaKey), hipMemcpyHostToDevice, ctx->stream));
+  const ChaChaKey *d_rk = (const ChaChaKey *)ctx->h_idx.p;
   const dim3 bgrid((unsigned)(P.n * 2 * P.l));
   switch (P.l) {
-    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
-    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
-    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, rk); break;
+    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
   }
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_gen_ksk, dim3((unsigned)((size_t)kN * P.t * base)), dim3(256), 0, ctx->stream, d_k0, d_k1,
-                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, rk);
+                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, d_rk);
   HIPCHK(ctx, hipGetLastError());
   // decomposition offset (key.rs:78-89) and test vector (key.rs:91-100)
   uint32_t off = 0;
@@ -666,6 +670,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   HIPCHK(ctx, hipMemsetAsync(ctx->h_a.p, 0, (size_t)P.n * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->h_b.p, 0, (size_t)kN * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->h_c.p, 0, (size_t)kN2 * sizeof(double2), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->h_idx.p, 0, sizeof(ChaChaKey), ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->offset = off;
   ctx->key_loaded = true;
