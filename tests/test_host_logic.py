@@ -219,3 +219,54 @@ def test_kernels_compile_without_scratch_and_keep_their_occupancy():
             assert o >= 2, (n, o)
         if "k_key_switch_b4" in n:
             assert o >= 3, (n, o)
+
+
+def test_keyed_engine_pool_logic(monkeypatch):
+    """bootstrap.keyed_engine (host logic, no GPU): a key stays resident in the context that holds it, an empty
+    context is preferred over a new one, at most MAX_ENGINES_PER_SET contexts exist per (parameter set, device), the
+    least recently used one is recycled beyond that, and key choice + use happen under the context's lock."""
+    import threading
+
+    from rs_tfhe_amd import bootstrap as B
+    from rs_tfhe_amd.params import SECURITY_128_BIT as P
+
+    created = []
+
+    class FakeEngine:
+        def __init__(self, params, device):
+            self.params, self.device = params, device
+            self._key, self._last_use, self.lock = None, 0, threading.RLock()
+            self.loads = 0
+            created.append(self)
+
+        def ensure_key(self, ck):
+            assert self.lock._is_owned()  # chosen and loaded inside one critical section
+            if self._key is not ck:
+                self._key = ck
+                self.loads += 1
+
+    class Key:
+        params = P
+
+    monkeypatch.setattr(B, "Engine", FakeEngine)
+    monkeypatch.setattr(B, "_engines", {})
+    keys = [Key() for _ in range(6)]
+    with B.keyed_engine(keys[0]) as e0:
+        assert e0._key is keys[0] and e0.lock._is_owned()
+    with B.keyed_engine(keys[0]) as again:
+        assert again is e0 and e0.loads == 1  # no re-upload
+    engines = []
+    for k in keys[1:4]:
+        with B.keyed_engine(k) as e:
+            engines.append(e)
+    assert len(created) == B.MAX_ENGINES_PER_SET == 4 and len(set(map(id, [e0] + engines))) == 4
+    with B.keyed_engine(keys[0]):  # touch key 0: key 1's context is now the least recently used
+        pass
+    with B.keyed_engine(keys[4]) as e:
+        assert e is engines[0] and e._key is keys[4] and len(created) == 4  # recycled, not grown
+    with B.keyed_engine(keys[0]) as e:
+        assert e is e0 and e0.loads == 1  # still resident
+    # another device gets its own pool
+    with B.keyed_engine(keys[5], device=1) as e:
+        assert e.device == 1 and len(created) == 5
+    assert B.engine_for(P, 0) is e0
