@@ -121,6 +121,17 @@ __global__ __launch_bounds__(64, 2) void k_mix(unsigned long long *clk, int iter
     w[i] = (int)threadIdx.x * 7 + i;
   }
   const unsigned lds_addr = (unsigned)(size_t)lds + threadIdx.x * 16;
+  double rnd[8];  // random mantissas, magnitudes alternating around 1 so that products stay bounded
+  {
+    unsigned long long x = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1) + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      const unsigned long long mant = x & 0x000FFFFFFFFFFFFFull;
+      const unsigned long long bits = ((i & 1) ? 0x3FE0000000000000ull : 0x3FF0000000000000ull) | mant | ((i & 2) ? 0x8000000000000000ull : 0ull);
+      rnd[i] = __longlong_as_double((long long)bits);
+    }
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
   for (int it = 0; it < iters; ++it) {
     if (MODE == 0) { body<FMA64>(d, w, c, lds_addr); body<FMA64>(d, w, c, lds_addr); }
@@ -137,6 +148,24 @@ __global__ __launch_bounds__(64, 2) void k_mix(unsigned long long *clk, int iter
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (MODE == 5) { body<FMA64>(d, w, c, lds_addr); body<ADD64>(d, w, c, lds_addr); }
+    if (MODE == 6) {  // FMAs on operands with full random mantissas: d[i] = d[i] * r[j] + r[k], |r| ~ 1, kept bounded by alternating signs
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]), "v"(rnd[(i + 3 + u) & 7]));
+    }
+    if (MODE == 7) {  // adds on random mantissas
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));
+    }
+    if (MODE == 8) {  // FMAs whose multiplier operand is the constant 2.0 (the Y = 2a - X half of the butterflies)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, 2.0, %0, %1" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));
+    }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
   double s = 0;
@@ -186,7 +215,7 @@ static void issue(unsigned long long *d_out, int waves) {
 
 template <int MODE>
 static void mix(unsigned long long *d_clk, const char *name, int cus, int rtc_khz, const std::vector<std::string> &pf) {
-  const int iters = 1200000;  // x 32 instructions x 4 cycles ~ 0.15 G cycles per wave; 2 waves per SIMD share the SIMD
+  const int iters = 6000000;  // x 32 instructions x 4 cycles ~ 0.15 G cycles per wave; 2 waves per SIMD share the SIMD
   CK(hipMemset(d_clk, 0, 64));
   std::atomic<bool> stop{false};
   std::vector<double> samples;
@@ -272,6 +301,9 @@ int main(int argc, char **argv) {
     mix<5>(d, "half v_fma_f64 half v_add_f64", prop.multiProcessorCount, rtc_khz, pf);
     mix<3>(d, "all v_add_u32", prop.multiProcessorCount, rtc_khz, pf);
     mix<4>(d, "v_fma_f64 + 4 LDS b128 per 32", prop.multiProcessorCount, rtc_khz, pf);
+    mix<6>(d, "v_fma_f64, random mantissas", prop.multiProcessorCount, rtc_khz, pf);
+    mix<7>(d, "v_add_f64, random mantissas", prop.multiProcessorCount, rtc_khz, pf);
+    mix<8>(d, "v_fma_f64 with multiplier 2.0", prop.multiProcessorCount, rtc_khz, pf);
   }
   return 0;
 }
