@@ -324,8 +324,8 @@ def main():
         # the same flops against the FP64 peak AT THE SUSTAINED CLOCK (the board is power-capped: DESIGN.md section 5)
         "frac_at_sustained_clock": round(tflops / (78.6 * shader_mhz / 2400.0), 4) if shader_mhz else None,
         # what this board sustains on nothing but v_fma_f64 over random operands (profiles/exp/logs/r2u_ubench_random_operands.log):
-        # the 1,400 W cap holds that stream at 2,189 MHz = 71.7 TFLOP/s
-        "frac_of_power_capped_fma_peak": round(tflops / 71.7, 4),
+        # the 1,400 W cap holds that stream at 2,027 MHz = 66.4 TFLOP/s
+        "frac_of_power_capped_fma_peak": round(tflops / 66.4, 4),
         "valu_issue_frac": round(wave_steps_per_s * isa["valu"] * 4 / simd_cycles_per_s, 4),
         "f64_issue_frac": round(wave_steps_per_s * f64_instr * 4 / simd_cycles_per_s, 4),
         # every bootstrap "consumes" the whole key once.  The key is shared through L1/L2, so this

@@ -128,7 +128,8 @@ __global__ __launch_bounds__(64, 2) void k_mix(unsigned long long *clk, int iter
     for (int i = 0; i < 8; ++i) {
       x ^= x << 13; x ^= x >> 7; x ^= x << 17;
       const unsigned long long mant = x & 0x000FFFFFFFFFFFFFull;
-      const unsigned long long bits = ((i & 1) ? 0x3FE0000000000000ull : 0x3FF0000000000000ull) | mant | ((i & 2) ? 0x8000000000000000ull : 0ull);
+      // |r| in [0.5, 1): d = d * r + r' is a contraction, so the operands stay finite with random mantissas forever
+      const unsigned long long bits = 0x3FE0000000000000ull | mant | ((i & 2) ? 0x8000000000000000ull : 0ull);
       rnd[i] = __longlong_as_double((long long)bits);
     }
   }
@@ -148,23 +149,29 @@ __global__ __launch_bounds__(64, 2) void k_mix(unsigned long long *clk, int iter
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     if (MODE == 5) { body<FMA64>(d, w, c, lds_addr); body<ADD64>(d, w, c, lds_addr); }
-    if (MODE == 6) {  // FMAs on operands with full random mantissas: d[i] = d[i] * r[j] + r[k], |r| ~ 1, kept bounded by alternating signs
+    if (MODE == 6) {  // FMAs on operands with full random mantissas: d[i] = d[i] * r[j] + r[k], |r| < 1 (bounded)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]), "v"(rnd[(i + 3 + u) & 7]));
     }
-    if (MODE == 7) {  // adds on random mantissas
+    if (MODE == 7) {  // adds on random mantissas: d[i] = r[j] - d[i] (bounded)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));
+        for (int i = 0; i < 16; ++i) asm volatile("v_add_f64 %0, %1, -%0" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));
+    }
+    if (MODE == 9) {  // multiplies on random mantissas: d[i] = r[j] * r[k] (fresh every time)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(d[i]) : "v"(rnd[(i + u) & 7]), "v"(rnd[(i + 3 + u) & 7]));
     }
     if (MODE == 8) {  // FMAs whose multiplier operand is the constant 2.0 (the Y = 2a - X half of the butterflies)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, 2.0, %0, %1" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));
+        for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, 2.0, %1, -%0" : "+v"(d[i]) : "v"(rnd[(i + u) & 7]));  // d = 2r - d (bounded)
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -304,6 +311,7 @@ int main(int argc, char **argv) {
     mix<6>(d, "v_fma_f64, random mantissas", prop.multiProcessorCount, rtc_khz, pf);
     mix<7>(d, "v_add_f64, random mantissas", prop.multiProcessorCount, rtc_khz, pf);
     mix<8>(d, "v_fma_f64 with multiplier 2.0", prop.multiProcessorCount, rtc_khz, pf);
+    mix<9>(d, "v_mul_f64, random mantissas", prop.multiProcessorCount, rtc_khz, pf);
   }
   return 0;
 }
