@@ -50,6 +50,7 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   HIPCHK(dst, hipMemcpyPeer(dst->d_ksk, dst->device, src->d_ksk, src->device, ksk_bytes));
   HIPCHK(dst, hipMemcpyPeer(dst->d_testvec, dst->device, src->d_testvec, src->device, 2 * kN * 4));
   HIPCHK(dst, hipDeviceSynchronize());
+  CHK(build_ksk_planes(dst));
   dst->offset = src->offset;
   dst->key_loaded = true;
   return TFHE_HIP_OK;

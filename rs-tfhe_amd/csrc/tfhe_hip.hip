@@ -22,6 +22,7 @@
 
 #include "blind_rotate.hpp"
 #include "key_switch.hpp"
+#include "key_switch_mfma.hpp"
 #include "keygen.hpp"
 #include "twiddles_host.hpp"
 
@@ -46,11 +47,12 @@ struct tfhe_hip_ctx {
   hipStream_t stream = nullptr;
   double2 *d_bsk = nullptr;
   uint32_t *d_ksk = nullptr;
+  unsigned char *d_ksk8 = nullptr;  // base-4 sets: the key as signed byte planes in MFMA fragment order (k_ksk_planes)
   uint32_t *d_testvec = nullptr;
   double2 *d_tw = nullptr;
   uint32_t offset = 0;
   bool key_loaded = false;
-  DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx;  // scratch / host-API staging
+  DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out;  // scratch / host-API staging
   std::mutex mu;
   std::string err = "";
   bool profiling = false;
@@ -58,6 +60,8 @@ struct tfhe_hip_ctx {
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
   bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
   int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
+  int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
+  size_t ks_mfma_min = 1024;  // smallest batch the matrix-core kernel takes (below: split / LDS-ring kernels)
   bool br_wide = true;      // small batches use the latency kernels
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
@@ -287,6 +291,80 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   return TFHE_HIP_OK;
 }
 
+// ---- base-4 key switch on the matrix cores (key_switch_mfma.hpp) -----------------------------------
+typedef void (*km_kernel_t)(const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t);
+// instantiated tile counts per column block (32 columns each, two blocks): n + 1 <= 64 * NT
+int ks_mfma_nt(int n) {
+  const int need = ks_mfma_tiles(n);
+  for (int nt : {3, 6, 9, 10, 11})
+    if (need <= nt) return nt;
+  return 0;
+}
+km_kernel_t km_kernel(int nt) {
+  switch (nt) {
+    case 3: return k_key_switch_mfma<3>;
+    case 6: return k_key_switch_mfma<6>;
+    case 9: return k_key_switch_mfma<9>;
+    case 10: return k_key_switch_mfma<10>;
+    case 11: return k_key_switch_mfma<11>;
+    default: return nullptr;
+  }
+}
+bool ks_mfma_possible(const tfhe_hip_ctx *ctx) {
+  return ctx->P.basebit == 2 && ctx->P.t >= 6 && ctx->P.t <= 13 && ks_mfma_nt(ctx->P.n) != 0;
+}
+bool ks_mfma_wanted(const tfhe_hip_ctx *ctx, size_t count) {
+  if (!ctx->d_ksk8 || !ctx->ks_mfma) return false;
+  return ctx->ks_mfma > 1 || count >= ctx->ks_mfma_min;
+}
+// rows of a level-1 buffer the matrix-core kernel may read: whole 256-row workgroups
+size_t lv1_rows(size_t count) { return (count + kKmRows - 1) / kKmRows * kKmRows; }
+
+// (re)build the byte planes from the u32 engine key; called wherever a key becomes current
+int build_ksk_planes(tfhe_hip_ctx *ctx) {
+  if (!ks_mfma_possible(ctx) || !ctx->ks_mfma) return TFHE_HIP_OK;
+  const tfhe_hip_params &P = ctx->P;
+  const int nt = ks_mfma_nt(P.n);
+  const size_t bytes = ks_mfma_key_bytes(P.n, P.t, nt);
+  if (!ctx->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk8, bytes));
+  HIPCHK(ctx, hipFuncSetAttribute((const void *)km_kernel(nt), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)ks_mfma_lds_bytes()));
+  const size_t chunks = bytes / 16;
+  hipLaunchKernelGGL(k_ksk_planes, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ksk,
+                     ctx->d_ksk8, P.n, P.t, nt, chunks);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return TFHE_HIP_OK;
+}
+
+int launch_key_switch_mfma(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
+  const int n = ctx->P.n, nt = ks_mfma_nt(n);
+  km_kernel_t kern = km_kernel(nt);
+  // the planes are merged with integer atomics: host (pinned, zero-copy) outputs go through a device buffer
+  uint32_t *dst = out;
+  hipPointerAttribute_t at;
+  const size_t obytes = count * (size_t)(n + 1) * 4;
+  bool host_out = false;
+  if (hipPointerGetAttributes(&at, (const void *)out) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(ctx, TFHE_HIP_EINVAL, "key switch output is not GPU-addressable memory");
+  }
+  if (at.type == hipMemoryTypeHost) {
+    host_out = true;
+    CHK(ensure(ctx, ctx->ks_out, obytes));
+    dst = (uint32_t *)ctx->ks_out.p;
+  }
+  HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
+  // one workgroup per (256 rows, column block, byte plane); consecutive workgroups walk the same key plane
+  const size_t rb = (count + kKmRows - 1) / kKmRows;
+  const size_t lds = ks_mfma_lds_bytes();
+  hipLaunchKernelGGL(kern, dim3((unsigned)rb, kKmColBlocks, 4), dim3(64 * kKmWaves), lds, s, lv1,
+                     (const unsigned char *)ctx->d_ksk8, n, ctx->P.t, dst, count);
+  HIPCHK(ctx, hipGetLastError());
+  if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
+  return TFHE_HIP_OK;
+}
+
 int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
   if (count == 0) return TFHE_HIP_OK;
   const int n = ctx->P.n;
@@ -301,6 +379,11 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
     hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->d_ksk,
                        (uint32_t)kb, n, ctx->P.basebit, ctx->P.t, out);
     HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_ks));
+    return TFHE_HIP_OK;
+  }
+  if (ks_mfma_wanted(ctx, count)) {
+    CHK(launch_key_switch_mfma(ctx, s, lv1, out, count));
     CHK(record_end(ctx, s, ctx->ev_ks));
     return TFHE_HIP_OK;
   }
@@ -351,7 +434,7 @@ int gate_dev(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b, 
   GatePrep gp;
   if (!gate_prep(gate, gp)) return fail(ctx, TFHE_HIP_EINVAL, "unknown gate");
   CHK(claim_scratch(ctx, s));
-  CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+  CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
 }
@@ -360,7 +443,7 @@ int gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, 
                     size_t count, hipStream_t s) {
   GatePrep gp{1u, 1u, 0u};  // placeholders; cb != 0 keeps in_b attached, the kernel reads the codes
   CHK(claim_scratch(ctx, s));
-  CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+  CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr, gates));
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
 }
@@ -378,7 +461,7 @@ int bootstrap_dev(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec
   gate_prep(TFHE_HIP_COPY, gp);
   if (keyswitch) {
     CHK(claim_scratch(ctx, s));
-    CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+    CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
     CHK(launch_blind_rotate(ctx, s, in, nullptr, gp, testvec, per_ct, count, nullptr,
                             (uint32_t *)ctx->lv1.p, nullptr));
     return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
@@ -391,7 +474,7 @@ int lincomb_bootstrap_dev(tfhe_hip_ctx *ctx, GatePrep gp, const uint32_t *a, con
                           hipStream_t s) {
   if (keyswitch) {
     CHK(claim_scratch(ctx, s));
-    CHK(ensure(ctx, ctx->lv1, count * (size_t)(kN + 1) * 4));
+    CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
     CHK(launch_blind_rotate(ctx, s, a, b, gp, testvec, per_ct, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr));
     return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
   }
@@ -524,6 +607,8 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_SLICED")) ctx->ks_sliced = atoi(env);
+  if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
+  if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
   ctx->wide_max = 2 * (size_t)ctx->num_cus;      // measured crossover vs the batch kernel: ~640 ciphertexts
   // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
   ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
@@ -557,11 +642,12 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
   }
-  DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx};
+  DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx, &ctx->ks_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   if (ctx->d_bsk) (void)hipFree(ctx->d_bsk);
   if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
+  if (ctx->d_ksk8) (void)hipFree(ctx->d_ksk8);
   if (ctx->d_testvec) (void)hipFree(ctx->d_testvec);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -615,6 +701,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, testvec, 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  CHK(build_ksk_planes(ctx));
   ctx->offset = decomp_offset;
   ctx->key_loaded = true;
   return TFHE_HIP_OK;
@@ -672,6 +759,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   HIPCHK(ctx, hipMemsetAsync(ctx->h_c.p, 0, (size_t)kN2 * sizeof(double2), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->h_idx.p, 0, sizeof(ChaChaKey), ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  CHK(build_ksk_planes(ctx));
   ctx->offset = off;
   ctx->key_loaded = true;
   return TFHE_HIP_OK;
@@ -791,6 +879,7 @@ int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
     return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_adopt_cloud_key before tfhe_hip_cloud_key_buffers");
   // whatever filled the buffers (a peer copy, an RCCL broadcast on another stream) must have finished
   HIPCHK(ctx, hipDeviceSynchronize());
+  CHK(build_ksk_planes(ctx));
   ctx->offset = decomp_offset;
   ctx->key_loaded = true;
   return TFHE_HIP_OK;
@@ -1116,6 +1205,7 @@ int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_l
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
   if (!tlwe_lv1 || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  CHK(ensure(ctx, ctx->h_a, lv1_rows(count) * (size_t)(kN + 1) * 4));  // whole 256-row groups readable (k_key_switch_mfma)
   CHK(to_dev(ctx, ctx->h_a, tlwe_lv1, count * (size_t)(kN + 1) * 4));
   const size_t obytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(ensure(ctx, ctx->h_out, obytes));

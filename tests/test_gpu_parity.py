@@ -184,6 +184,10 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_128_BIT", {}),                                # k_key_switch_b4 (LDS ring, base 4)
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_B4": "0"}),           # k_key_switch (generic, buffer loads)
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_SLICED": "2"}),       # k_key_switch_sliced forced at base 4
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<11> (int8 matrix cores), t = 9
+    ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<10>, t = 8
+    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<9>, t = 7
+    ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<11>, t = 8
     ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32)
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
     ("SECURITY_UINT2", {}),                                  # base 16
@@ -205,7 +209,7 @@ def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, env):
     eng = R.Engine(pk.params, 0)
     eng.load_cloud_key(pk)
     rng = np.random.default_rng(27)
-    for count in (1, 33, 515):
+    for count in (1, 33, 515) + ((1300,) if "TFHE_HIP_KS_MFMA" in env else ()):  # 256-row workgroups of the MFMA kernel
         lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
         lv1[0, :N] = 0
         lv1[-1, :N] = 0xFFFFFFFF
