@@ -313,6 +313,9 @@ typedef struct tfhe_hip_clock_sample {
   uint64_t rtc_ticks;
 } tfhe_hip_clock_sample;
 int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
+/* The same sample for the matrix-core key switch (k_key_switch_mfma; the other key-switch kernels do not
+ * sample): the clock that prices it against the int8 MFMA roofline. */
+int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
 
 /* Block until everything this context enqueued -- on its own stream and on the caller's stream of the
  * last *_dev call -- has finished.  Returns TFHE_HIP_EINVAL (and clears the condition) if a

@@ -92,6 +92,7 @@ SIGNATURES = {
     "tfhe_hip_set_profiling": (C.c_int, [_CTX, C.c_int]),
     "tfhe_hip_get_kernel_times": (C.c_int, [_CTX, C.POINTER(KernelTimes)]),
     "tfhe_hip_get_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
+    "tfhe_hip_get_key_switch_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
     # several GPUs behind one handle
     "tfhe_hip_pool_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(_CTX)]),

@@ -34,28 +34,44 @@
 
 namespace tfhe {
 
-constexpr int kKmRows = 256;             // ciphertexts per workgroup
-constexpr int kKmWaves = 8;              // 32 rows each: 2 waves per SIMD, 16*NT accumulator registers per wave
+#ifndef TFHE_KM_FRAGS  // experiment knobs (profiles/exp/build_variants.sh); the defaults are the product
+#define TFHE_KM_FRAGS 2
+#endif
+#ifndef TFHE_KM_COLBLOCKS
+#define TFHE_KM_COLBLOCKS 4
+#endif
+constexpr int kKmWaves = 4;              // waves per workgroup (two workgroups per CU: 2 waves per SIMD)
+constexpr int kKmFrags = TFHE_KM_FRAGS;  // 32-row A fragments per wave: a key tile read from LDS feeds this many matrix instructions
+constexpr int kKmRows = 32 * kKmFrags * kKmWaves;  // ciphertexts per workgroup; level-1 buffers are padded to a multiple
 constexpr int kKmSlots = 4;              // ring depth in K-steps
 constexpr int kKmAhead = kKmSlots - 1;   // DMA lead in K-steps
-constexpr int kKmSlotTiles = 16;         // tile positions per slot (2 per wave)
-constexpr int kKmSlotBytes = kKmSlotTiles * 1024;
-constexpr int kKmAbBytes = 32 * 16 * 4;  // one wave's a_bar stage: 32 rows x 16 coefficients
+constexpr int kKmAbBytes = 32 * kKmFrags * 16 * 4;  // one wave's a_bar stage: its rows x 16 coefficients
 constexpr int kKmAbQ = kKmAbBytes / 256; // dword DMA instructions per stage (256 B each)
-constexpr int kKmOpsPerStep = 3;         // per wave per K-step: 2 key tiles + 1 a_bar piece
-constexpr int kKmColBlocks = 2;
+constexpr int kKmColBlocks = TFHE_KM_COLBLOCKS;
+constexpr int kKmMaxTiles = 12 / kKmFrags;  // accumulator budget: kKmFrags x NT x 16 registers <= 192 (two waves per SIMD)
 
-__host__ __device__ __forceinline__ size_t ks_mfma_lds_bytes() {
-  return (size_t)kKmSlots * kKmSlotBytes + kKmWaves * 2 * kKmAbBytes + kKmWaves * 256;
+// key tiles a wave copies per K-step, tile positions per ring slot
+__host__ __device__ constexpr int ks_mfma_tpw(int nt) { return (nt + kKmWaves - 1) / kKmWaves; }
+__host__ __device__ constexpr int ks_mfma_slot_bytes(int nt) { return ks_mfma_tpw(nt) * kKmWaves * 1024; }
+__host__ __device__ constexpr size_t ks_mfma_lds_bytes(int nt) {
+  return (size_t)kKmSlots * ks_mfma_slot_bytes(nt) + (size_t)kKmWaves * 2 * kKmAbBytes + (size_t)kKmWaves * 256;
 }
-// 32-column tiles per column block for n+1 output words
-__host__ __device__ __forceinline__ int ks_mfma_tiles(int n) {
-  const int tiles = (n + 1 + 31) / 32;
-  return (tiles + kKmColBlocks - 1) / kKmColBlocks;
+// The ceil((n+1)/32) column tiles are dealt to the column blocks as evenly as possible: the first `tiles % 4`
+// blocks hold one more than the others.  ks_mfma_tiles = the larger count (the kernel's NT).
+__host__ __device__ __forceinline__ int ks_mfma_total_tiles(int n) { return (n + 1 + 31) / 32; }
+__host__ __device__ __forceinline__ int ks_mfma_tiles(int n) { return (ks_mfma_total_tiles(n) + kKmColBlocks - 1) / kKmColBlocks; }
+__host__ __device__ __forceinline__ int ks_mfma_block_tiles(int n, int cb) {
+  const int tiles = ks_mfma_total_tiles(n);
+  return tiles / kKmColBlocks + (cb < tiles % kKmColBlocks ? 1 : 0);
 }
-__host__ __device__ __forceinline__ size_t ks_mfma_key_bytes(int n, int t, int nt) {
-  return (size_t)4 * kKmColBlocks * (64 * 2 * t) * nt * 1024;
+__host__ __device__ __forceinline__ int ks_mfma_block_first(int n, int cb) {  // first tile of column block cb
+  const int tiles = ks_mfma_total_tiles(n), base = tiles / kKmColBlocks, rem = tiles % kKmColBlocks;
+  return cb * base + (cb < rem ? cb : rem);
 }
+__host__ __device__ __forceinline__ size_t ks_mfma_key_bytes(int n, int t) {
+  return (size_t)4 * (64 * 2 * t) * ks_mfma_total_tiles(n) * 1024;
+}
+constexpr size_t kKmKeyTailPad = 64 * 1024;  // the DMA lead runs kKmAhead steps (<= 8 KiB each) past the last plane
 
 // Balanced signed byte p of w: w = sum_p s_p 256^p (mod 2^32), s_p in [-128, 127].
 __host__ __device__ __forceinline__ uint32_t ks_plane_byte(uint32_t w, int p) {
@@ -69,22 +85,25 @@ __host__ __device__ __forceinline__ uint32_t ks_plane_byte(uint32_t w, int p) {
 }
 
 // u32 engine layout [N*t*4][RW] -> byte planes in MFMA fragment order:
-//   [plane p][column block cb][K-step s][tile c][lane][16 B],  s = blk*2t + 2j + hh  (blk: 16-coefficient block,
-//   j: digit position, hh: which 8 coefficients), lane = (column in tile = lane & 31, kb = lane >> 5),
+//   [plane p][column block cb][K-step s][tile c < block tiles][lane][16 B],  s = blk*2t + 2j + hh  (blk: 16-coefficient
+//   block, j: digit position, hh: which 8 coefficients), lane = (column in tile = lane & 31, kb = lane >> 5),
 //   byte 4cc + k = plane byte of key row (i = 16 blk + 8 hh + 4 kb + cc, j, k) at that column.
-__global__ void k_ksk_planes(const uint32_t *__restrict__ eng, unsigned char *__restrict__ out, int n, int t, int nt,
+__global__ void k_ksk_planes(const uint32_t *__restrict__ eng, unsigned char *__restrict__ out, int n, int t,
                              size_t chunks) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= chunks) return;
   const int lane = (int)(idx & 63);
-  size_t r = idx >> 6;
-  const int c = (int)(r % (size_t)nt);
-  r /= (size_t)nt;
-  const int S = 64 * 2 * t;
-  const int s = (int)(r % (size_t)S);
-  r /= (size_t)S;
-  const int cb = (int)(r % kKmColBlocks), p = (int)(r / kKmColBlocks);
-  const int col = (cb * nt + c) * 32 + (lane & 31), kb = lane >> 5;
+  size_t r = idx >> 6;  // (p, cb, s, c) with a per-block tile count
+  const int S = 64 * 2 * t, tiles = ks_mfma_total_tiles(n);
+  const size_t per_plane = (size_t)S * tiles;
+  const int p = (int)(r / per_plane);
+  r -= (size_t)p * per_plane;
+  int cb = 0;
+  while (cb + 1 < kKmColBlocks && r >= (size_t)S * ks_mfma_block_first(n, cb + 1)) ++cb;
+  r -= (size_t)S * ks_mfma_block_first(n, cb);
+  const int nt = ks_mfma_block_tiles(n, cb);
+  const int s = (int)(r / (size_t)nt), c = (int)(r % (size_t)nt);
+  const int col = (ks_mfma_block_first(n, cb) + c) * 32 + (lane & 31), kb = lane >> 5;
   const int blk = s / (2 * t), u = s % (2 * t), j = u >> 1, hh = u & 1;
   const int rw = (n + 1 + 3) & ~3;
   uint32_t o[4];
@@ -107,43 +126,21 @@ using km_i32x4 = __attribute__((ext_vector_type(4))) int;
 using km_i32x16 = __attribute__((ext_vector_type(16))) int;
 using km_u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-// One K-step's DMAs of one wave, as ONE asm statement (M0 is saved and restored around it; hipcc does not
-// model M0 as clobberable).  Two 1-KiB pieces of the key tile row + one 256-byte piece of a_bar words.
-__device__ __forceinline__ void km_dma_step(uint32_t v16, const void *b0, const void *b1, uint32_t l0, uint32_t l1,
-                                            uint32_t v4, const void *a0, uint32_t la0) {
+// global -> LDS DMA: 64 lanes x 16 B (4 B) from sbase + voff to LDS address `lds` + lane x 16 (4); inline asm so that
+// hipcc neither drains it with vmcnt(0) at the next LDS read nor loses track of M0 (saved and restored here)
+__device__ __forceinline__ void km_dma16(uint32_t voff, const void *sbase, uint32_t lds) {
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %4\n\t"
+      "s_mov_b32 m0, %3\n\t"
       "s_nop 0\n\t"
       "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %5\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "s_mov_b32 m0, %8\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dword %6, %7\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(v16), "s"(b0), "s"(b1), "s"(l0), "s"(l1), "v"(v4), "s"(a0), "s"(la0)
+      : "v"(voff), "s"(sbase), "s"(lds)
       : "memory");
 }
-__device__ __forceinline__ void km_dma_b2(uint32_t v16, const void *b0, const void *b1, uint32_t l0, uint32_t l1) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %4\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %2\n\t"
-      "s_mov_b32 m0, %5\n\t"
-      "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, %3\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(v16), "s"(b0), "s"(b1), "s"(l0), "s"(l1)
-      : "memory");
-}
-__device__ __forceinline__ void km_dma_a1(uint32_t v4, const void *a0, uint32_t la0) {
+__device__ __forceinline__ void km_dma4(uint32_t voff, const void *sbase, uint32_t lds) {
   uint32_t keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\t"
@@ -152,7 +149,7 @@ __device__ __forceinline__ void km_dma_a1(uint32_t v4, const void *a0, uint32_t 
       "global_load_lds_dword %1, %2\n\t"
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(v4), "s"(a0), "s"(la0)
+      : "v"(voff), "s"(sbase), "s"(lds)
       : "memory");
 }
 
@@ -161,132 +158,177 @@ struct KmPos {
   int blk, u;
 };
 
-// lv1 must be readable for count rounded up to kKmRows rows (rows past count are computed and dropped).
-// out must be zero on entry: the four byte planes (blockIdx.z) are merged with integer atomics (u32 addition
-// commutes: same bits in any arrival order).
+// A workgroup = kKmWaves waves x kKmFrags x 32 rows, one column block, one byte plane.  lv1 must be readable for
+// count rounded up to kKmRows rows (rows past count are computed and dropped).  out must be zero on entry: the four
+// byte planes (blockIdx.z) are merged with integer atomics (u32 addition commutes: same bits in any arrival order).
+// NT = tiles of the widest column block; a block with NT-1 tiles skips the last tile (wave-uniform branch).
 template <int NT>
 __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint32_t *__restrict__ lv1,        // [count][N+1]
                                                                        const unsigned char *__restrict__ ksk8,  // k_ksk_planes layout
                                                                        int n, int t, uint32_t *__restrict__ out,  // [count][n+1]
-                                                                       size_t count) {
-  constexpr int N = 1024, D = kKmAhead;
-  static_assert(NT <= kKmSlotTiles, "slot too small");
+                                                                       size_t count,
+                                                                       unsigned long long *clk) {  // optional [2]: += shader cycles, += constant-rate ticks
+  constexpr int N = 1024, D = kKmAhead, WAVES = kKmWaves, R = kKmFrags;
+  constexpr int TPW = ks_mfma_tpw(NT), SLOT = ks_mfma_slot_bytes(NT), OPS = TPW + R;
+  const unsigned long long clk0 = clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rtc0 = clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
   extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)km_smem;
-  const uint32_t off_ab = (uint32_t)(kKmSlots * kKmSlotBytes) + (uint32_t)wave * 2u * kKmAbBytes;
-  const uint32_t off_dump = (uint32_t)(kKmSlots * kKmSlotBytes) + (uint32_t)(kKmWaves * 2 * kKmAbBytes) + (uint32_t)wave * 256u;
-  const size_t row0 = (size_t)blockIdx.x * kKmRows + (size_t)wave * 32;  // this wave's 32 rows
+  const uint32_t off_ab = (uint32_t)(kKmSlots * SLOT) + (uint32_t)wave * 2u * kKmAbBytes;
+  const uint32_t off_dump = (uint32_t)(kKmSlots * SLOT) + (uint32_t)(WAVES * 2 * kKmAbBytes) + (uint32_t)wave * 256u;
+  const size_t row0 = (size_t)blockIdx.x * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
   const int cb = blockIdx.y, plane = blockIdx.z;  // one byte plane per workgroup: no epilogue inside the K loop
+  const int nt_blk = ks_mfma_block_tiles(n, cb), tile0 = ks_mfma_block_first(n, cb);
+  const bool full = nt_blk == NT;  // wave-uniform
   const int spb = 2 * t, S = 64 * spb;  // steps per block, per plane
   const uint32_t prec = 1u << (31 - 2 * t);
   const uint32_t v16 = (uint32_t)lane * 16u;
-  // a_bar DMA op q of a block: rows 4q + (lane >> 4), coefficient 16 blk + (lane & 15)
+  // a_bar DMA piece q of a block: rows 4q + (lane >> 4), coefficient 16 blk + (lane & 15)
   const uint32_t v4 = (uint32_t)(((lane >> 4) * (N + 1) + (lane & 15)) * 4);
   const uint32_t *ab_row0 = lv1 + row0 * (size_t)(N + 1);
-  // key tiles this wave copies per step: wave, wave + 8 (clamped past NT: lands in a position nobody reads)
-  const int tc0 = wave < NT ? wave : NT - 1, tc1 = wave + 8 < NT ? wave + 8 : NT - 1;
 
-  // (past the last step the walk wraps to step 0: a harmless re-read into a slot nobody reads any more)
-  const unsigned char *kplane = ksk8 + (size_t)(plane * kKmColBlocks + cb) * S * ((size_t)NT * 1024);
-  auto key_step = [&](const KmPos &q) -> const unsigned char * {
-    return kplane + (size_t)(q.blk * spb + q.u) * ((size_t)NT * 1024);
-  };
-  auto advance = [&](KmPos &q) {
-    if (++q.u == spb) {
-      q.u = 0;
-      if (++q.blk == 64) q.blk = 0;
+  // The key tiles of this workgroup's (plane, column block) are one contiguous stream, nt_blk KiB per K-step: a DMA
+  // source is the stream base (SGPRs) + a per-lane 32-bit offset that advances by nt_blk KiB per step.  The D steps
+  // fetched past the end of the walk read the next block (or the allocation's tail pad) into slots nobody reads.
+  const unsigned char *kplane = ksk8 + ((size_t)plane * ks_mfma_total_tiles(n) + (size_t)tile0) * S * 1024;
+  uint32_t koff[TPW];  // this wave's tiles: wave, wave + WAVES, ... (clamped past nt_blk: lands in a position nobody reads)
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int tile = wave + i * WAVES;
+    koff[i] = (uint32_t)(tile < nt_blk ? tile : nt_blk - 1) * 1024u + v16;
+  }
+  const uint32_t kstride = (uint32_t)nt_blk * 1024u;
+  auto dma_key = [&](uint32_t slot) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      km_dma16(koff[i], kplane, slot + (uint32_t)(wave + i * WAVES) * 1024u);
+      koff[i] += kstride;
     }
   };
 
   // ---- prologue: a_bar block 0, key steps 0 .. D-1 ---------------------------------------------
-  for (int q = 0; q < kKmAbQ; ++q) km_dma_a1(v4, ab_row0 + (size_t)(4 * q) * (N + 1), lds_base + off_ab + (uint32_t)q * 256u);
-  KmPos pf{0, 0};  // next step to prefetch
-  for (int d = 0; d < D; ++d) {
-    const unsigned char *kb = key_step(pf);
-    const uint32_t slot = lds_base + (uint32_t)d * kKmSlotBytes;
-    km_dma_b2(v16, kb + tc0 * 1024, kb + tc1 * 1024, slot + (uint32_t)wave * 1024u, slot + (uint32_t)(wave + 8) * 1024u);
-    advance(pf);
-  }
+  for (int q = 0; q < kKmAbQ; ++q) km_dma4(v4, ab_row0 + (size_t)(4 * q) * (N + 1), lds_base + off_ab + (uint32_t)q * 256u);
+  for (int d = 0; d < D; ++d) dma_key(lds_base + (uint32_t)d * SLOT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
-  km_i32x16 acc[NT];
-  KmPos cur{0, 0};
+  km_i32x16 acc[R][NT];
   const uint32_t a_lane = (uint32_t)((lane & 31) * 64 + (lane >> 5) * 16);  // this lane's 4 words in a stage row
-#pragma unroll
-  for (int c = 0; c < NT; ++c) acc[c] = km_i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 1
-  for (int g = 0; g < S; ++g) {
-    // my pieces of step g have landed (the D-1 younger groups may be in flight); after the barrier everybody's
-    // have, and everybody is done reading the slot of step g-1, which the next DMA group refills
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * kKmOpsPerStep) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    {
-      const unsigned char *kb = key_step(pf);
-      const uint32_t slot = lds_base + (uint32_t)((g + D) % kKmSlots) * kKmSlotBytes;
-      // a_bar words of the NEXT block into the other stage buffer: op u of the block (real while < kKmAbQ)
-      const int nblk = (cur.blk + 1) & 63;
-      const uint32_t nbuf = lds_base + off_ab + (uint32_t)((cur.blk + 1) & 1) * kKmAbBytes;
-      const int q0 = cur.u;
-      const uint32_t *s0 = ab_row0 + (size_t)(4 * (q0 & (kKmAbQ - 1))) * (N + 1) + 16 * nblk;
-      const uint32_t d0 = q0 < kKmAbQ ? nbuf + (uint32_t)q0 * 256u : lds_base + off_dump;
-      km_dma_step(v16, kb + tc0 * 1024, kb + tc1 * 1024, slot + (uint32_t)wave * 1024u, slot + (uint32_t)(wave + 8) * 1024u,
-                  v4, s0, d0);
-      advance(pf);
-    }
-    // ---- A fragment of this step: digit position j of coefficients 16 blk + 8 hh + 4 kb + (0..3) ----
-    const int j = cur.u >> 1, hh = cur.u & 1;
-    const uint32_t sh = (uint32_t)(27 - 2 * j);  // ((a_bar >> (30 - 2j)) & 3) * 8
-    const unsigned char *abuf = km_smem + off_ab + (uint32_t)(cur.blk & 1) * kKmAbBytes + a_lane + (uint32_t)hh * 32u;
-    const km_u32x4 w = *reinterpret_cast<const km_u32x4 *>(abuf);
+  // A fragment f of step (blk, u): digit position j = u >> 1 of coefficients 16 blk + 8 (u & 1) + 4 kb + (0..3)
+  auto make_a = [&](const KmPos &q, int f) -> km_i32x4 {
+    const uint32_t sh = (uint32_t)(27 - 2 * (q.u >> 1));  // ((a_bar >> (30 - 2j)) & 3) * 8
+    const unsigned char *abuf = km_smem + off_ab + (uint32_t)(q.blk & 1) * kKmAbBytes + a_lane + (uint32_t)(q.u & 1) * 32u;
+    const km_u32x4 w = *reinterpret_cast<const km_u32x4 *>(abuf + f * (32 * 64));
     km_u32x4 a;
     a.x = 1u << (((w.x + prec) >> sh) & 0x18u);
     a.y = 1u << (((w.y + prec) >> sh) & 0x18u);
     a.z = 1u << (((w.z + prec) >> sh) & 0x18u);
     a.w = 1u << (((w.w + prec) >> sh) & 0x18u);
-    const km_i32x4 A = __builtin_bit_cast(km_i32x4, a);
-    const unsigned char *slot = km_smem + (uint32_t)(g % kKmSlots) * kKmSlotBytes + v16;
+    return __builtin_bit_cast(km_i32x4, a);
+  };
+  KmPos cur{0, 0};
+  km_i32x4 A[R];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      const km_i32x4 B = *reinterpret_cast<const km_i32x4 *>(slot + c * 1024);
-      acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, B, acc[c], 0, 0, 0);
+  for (int f = 0; f < R; ++f) A[f] = make_a(cur, f);
+  constexpr int PRE = NT < 3 ? NT : 3;  // key tiles of a step read before its first matrix instruction
+  constexpr int H = NT / 2;             // tiles consumed before the mid-step barrier
+  km_i32x4 Bpre[PRE];
+#pragma unroll
+  for (int c = 0; c < PRE; ++c) Bpre[c] = *reinterpret_cast<const km_i32x4 *>(km_smem + v16 + c * 1024);
+#pragma unroll
+  for (int f = 0; f < R; ++f)
+#pragma unroll
+    for (int c = 0; c < NT; ++c) acc[f][c] = km_i32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // Step g consumes slot g % 4.  The hand-over of step g+1 sits in the MIDDLE of step g: by then my own pieces of
+  // step g+1 have landed (one younger DMA group may be in flight), after the barrier everybody's have, and everybody
+  // is done with step g-1, whose slot the next DMA group refills.  So the first key tiles of step g+1 and its A
+  // fragments are fetched under the second half of step g's matrix instructions and no wave starts a step waiting.
+#pragma unroll 1
+  for (int g = 0; g < S; ++g) {
+    const unsigned char *slot = km_smem + (uint32_t)(g % kKmSlots) * SLOT + v16;
+    const unsigned char *slot_next = km_smem + (uint32_t)((g + 1) % kKmSlots) * SLOT + v16;
+    km_i32x4 B[NT];
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) B[c] = Bpre[c];
+#pragma unroll
+    for (int c = 0; c < H; ++c) {
+      if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
+#pragma unroll
+      for (int f = 0; f < R; ++f) acc[f][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[f], B[c], acc[f][c], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * OPS) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {
+      dma_key(lds_base + (uint32_t)((g + D) % kKmSlots) * SLOT);
+      // a_bar words of the NEXT block into the other stage buffer: pieces R*u .. R*u + R-1 of the block (real while
+      // < kKmAbQ; the last real one is issued at step 7 of a block, >= D steps before the next block's first fragment)
+      const int nblk = (cur.blk + 1) & 63;
+      const uint32_t nbuf = lds_base + off_ab + (uint32_t)((cur.blk + 1) & 1) * kKmAbBytes;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int q0 = R * cur.u + r;
+        const uint32_t *s0 = ab_row0 + (size_t)(4 * (q0 & (kKmAbQ - 1))) * (N + 1) + 16 * nblk;
+        const uint32_t d0 = q0 < kKmAbQ ? nbuf + (uint32_t)q0 * 256u : lds_base + off_dump;
+        km_dma4(v4, s0, d0);
+      }
     }
     if (++cur.u == spb) {
       cur.u = 0;
       cur.blk = (cur.blk + 1) & 63;
     }
+    km_i32x4 A_next[R];
+#pragma unroll
+    for (int f = 0; f < R; ++f) A_next[f] = make_a(cur, f);
+#pragma unroll
+    for (int c = H; c < NT; ++c) {
+      if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
+      if (c < NT - 1 || full) {
+#pragma unroll
+        for (int f = 0; f < R; ++f) acc[f][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[f], B[c], acc[f][c], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < PRE; ++c) Bpre[c] = *reinterpret_cast<const km_i32x4 *>(slot_next + c * 1024);
+#pragma unroll
+    for (int f = 0; f < R; ++f) A[f] = A_next[f];
   }
   // ---- merge this plane into the output ---------------------------------------------------------------
-  // C tile element e of lane: row (e&3) + 8(e>>2) + 4(lane>>5), column 32c + (lane&31).  An address is one
+  // C tile element e of lane: row 32f + (e&3) + 8(e>>2) + 4(lane>>5), column 32c + (lane&31).  An address is one
   // per-lane offset + a wave-uniform one.
   {
     const int sh8 = 8 * plane;
-    const int row_lim = (int)(count > row0 ? (count - row0 < 32 ? count - row0 : 32) : 0) - 4 * (lane >> 5);  // valid e-rows: < row_lim
-    const int col_lane = cb * NT * 32 + (lane & 31);
+    const int row_lim = (int)(count > row0 ? (count - row0 < 32 * R ? count - row0 : 32 * R) : 0) - 4 * (lane >> 5);  // valid e-rows: < row_lim
+    const int col_lane = tile0 * 32 + (lane & 31);
     const uint32_t lane_off = (uint32_t)((4 * (lane >> 5)) * (n + 1) + col_lane) * 4u;
     unsigned char *obase = reinterpret_cast<unsigned char *>(out + row0 * (size_t)(n + 1));
     const uint32_t row_bytes = (uint32_t)(n + 1) * 4u;
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
-      const bool col_ok = col_lane + 32 * c <= n;
-      const bool is_body = col_lane + 32 * c == n && plane == 0;
+    for (int f = 0; f < R; ++f)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int er = (e & 3) + 8 * (e >> 2);
-        if (col_ok && er < row_lim) {
-          uint32_t v = 0u - ((uint32_t)acc[c][e] << sh8);
-          if (is_body) v += lv1[(row0 + (size_t)(er + 4 * (lane >> 5))) * (size_t)(N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
-          unsigned char *uni = obase + (size_t)((uint32_t)er * row_bytes + (uint32_t)(c * 128));
-          if (v) atomicAdd(reinterpret_cast<uint32_t *>(uni + lane_off), v);
+      for (int c = 0; c < NT; ++c) {
+        const bool col_ok = col_lane + 32 * c <= n && c < nt_blk;
+        const bool is_body = col_lane + 32 * c == n && plane == 0;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int er = 32 * f + (e & 3) + 8 * (e >> 2);
+          if (col_ok && er < row_lim) {
+            uint32_t v = 0u - ((uint32_t)acc[f][c][e] << sh8);
+            if (is_body) v += lv1[(row0 + (size_t)(er + 4 * (lane >> 5))) * (size_t)(N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+            unsigned char *uni = obase + (size_t)((uint32_t)er * row_bytes + (uint32_t)(c * 128));
+            if (v) atomicAdd(reinterpret_cast<uint32_t *>(uni + lane_off), v);
+          }
         }
       }
-    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (wrapped) DMAs before the LDS goes away
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing DMAs before the LDS goes away
+  if (clk && tid == 0) {
+    atomicAdd(&clk[0], __builtin_amdgcn_s_memtime() - clk0);
+    atomicAdd(&clk[1], __builtin_amdgcn_s_memrealtime() - rtc0);
+  }
 }
 
 }  // namespace tfhe

@@ -71,7 +71,8 @@ struct tfhe_hip_ctx {
   hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
   bool scratch_owned = false;
   // device diagnostics: [0] shader cycles, [1] constant-rate ticks (both summed over blind-rotate
-  // workgroups while profiling is on), [2] error flag raised by kernels (bad gate code)
+  // workgroups while profiling is on), [2] error flag raised by kernels (bad gate code), [4] / [5] the same two
+  // sums for the matrix-core key switch
   unsigned long long *d_diag = nullptr;
   int rtc_khz = 100000;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
 };
@@ -292,24 +293,18 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
 }
 
 // ---- base-4 key switch on the matrix cores (key_switch_mfma.hpp) -----------------------------------
-typedef void (*km_kernel_t)(const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t);
-// instantiated tile counts per column block (32 columns each, two blocks): n + 1 <= 64 * NT
+typedef void (*km_kernel_t)(const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t, unsigned long long *);
+// instantiated tile counts of the widest column block (32 columns each): 1 .. kKmMaxTiles
 int ks_mfma_nt(int n) {
   const int need = ks_mfma_tiles(n);
-  for (int nt : {3, 6, 9, 10, 11})
-    if (need <= nt) return nt;
-  return 0;
+  return (need >= 1 && need <= kKmMaxTiles) ? need : 0;
 }
-km_kernel_t km_kernel(int nt) {
-  switch (nt) {
-    case 3: return k_key_switch_mfma<3>;
-    case 6: return k_key_switch_mfma<6>;
-    case 9: return k_key_switch_mfma<9>;
-    case 10: return k_key_switch_mfma<10>;
-    case 11: return k_key_switch_mfma<11>;
-    default: return nullptr;
-  }
+template <int NT>
+km_kernel_t km_kernel_from(int nt) {
+  if constexpr (NT > kKmMaxTiles) return nullptr;
+  else return nt == NT ? (km_kernel_t)k_key_switch_mfma<NT> : km_kernel_from<NT + 1>(nt);
 }
+km_kernel_t km_kernel(int nt) { return km_kernel_from<1>(nt); }
 bool ks_mfma_possible(const tfhe_hip_ctx *ctx) {
   return ctx->P.basebit == 2 && ctx->P.t >= 6 && ctx->P.t <= 13 && ks_mfma_nt(ctx->P.n) != 0;
 }
@@ -325,13 +320,13 @@ int build_ksk_planes(tfhe_hip_ctx *ctx) {
   if (!ks_mfma_possible(ctx) || !ctx->ks_mfma) return TFHE_HIP_OK;
   const tfhe_hip_params &P = ctx->P;
   const int nt = ks_mfma_nt(P.n);
-  const size_t bytes = ks_mfma_key_bytes(P.n, P.t, nt);
-  if (!ctx->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk8, bytes));
+  const size_t bytes = ks_mfma_key_bytes(P.n, P.t);
+  if (!ctx->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk8, bytes + kKmKeyTailPad));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)km_kernel(nt), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ks_mfma_lds_bytes()));
+                                  (int)ks_mfma_lds_bytes(nt)));
   const size_t chunks = bytes / 16;
   hipLaunchKernelGGL(k_ksk_planes, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ksk,
-                     ctx->d_ksk8, P.n, P.t, nt, chunks);
+                     ctx->d_ksk8, P.n, P.t, chunks);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_HIP_OK;
@@ -357,9 +352,11 @@ int launch_key_switch_mfma(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1
   HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
   // one workgroup per (256 rows, column block, byte plane); consecutive workgroups walk the same key plane
   const size_t rb = (count + kKmRows - 1) / kKmRows;
-  const size_t lds = ks_mfma_lds_bytes();
-  hipLaunchKernelGGL(kern, dim3((unsigned)rb, kKmColBlocks, 4), dim3(64 * kKmWaves), lds, s, lv1,
-                     (const unsigned char *)ctx->d_ksk8, n, ctx->P.t, dst, count);
+  const size_t lds = ks_mfma_lds_bytes(nt);
+  const int tiles = ks_mfma_total_tiles(n);
+  hipLaunchKernelGGL(kern, dim3((unsigned)rb, (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks), 4), dim3(64 * kKmWaves), lds, s, lv1,
+                     (const unsigned char *)ctx->d_ksk8, n, ctx->P.t, dst, count,
+                     ctx->profiling ? ctx->d_diag + 4 : nullptr);
   HIPCHK(ctx, hipGetLastError());
   if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
   return TFHE_HIP_OK;
@@ -595,8 +592,8 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (dg.err != hipSuccess) return bail("hipSetDevice", dg.err);
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", e);
-  if ((e = hipMalloc((void **)&ctx->d_diag, 32)) != hipSuccess) return bail("hipMalloc diagnostics", e);
-  if ((e = hipMemset(ctx->d_diag, 0, 32)) != hipSuccess) return bail("hipMemset diagnostics", e);
+  if ((e = hipMalloc((void **)&ctx->d_diag, 64)) != hipSuccess) return bail("hipMalloc diagnostics", e);
+  if ((e = hipMemset(ctx->d_diag, 0, 64)) != hipSuccess) return bail("hipMemset diagnostics", e);
   if (hipDeviceGetAttribute(&ctx->rtc_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || ctx->rtc_khz <= 0)
     ctx->rtc_khz = 100000;
   hipDeviceProp_t prop;
@@ -1260,7 +1257,10 @@ int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
 int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled) {
   if (!ctx) return TFHE_HIP_EINVAL;
   ENTER(ctx);
-  if (enabled && !ctx->profiling) HIPCHK(ctx, hipMemsetAsync(ctx->d_diag, 0, 16, ctx->stream));
+  if (enabled && !ctx->profiling) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_diag, 0, 16, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_diag + 4, 0, 16, ctx->stream));
+  }
   ctx->profiling = enabled != 0;
   return TFHE_HIP_OK;
 }
@@ -1297,6 +1297,21 @@ int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out) {
   unsigned long long h[2] = {0, 0};
   HIPCHK(ctx, hipMemcpy(h, ctx->d_diag, 16, hipMemcpyDeviceToHost));
   HIPCHK(ctx, hipMemset(ctx->d_diag, 0, 16));
+  out->shader_cycles = h[0];
+  out->rtc_ticks = h[1];
+  out->rtc_mhz = ctx->rtc_khz / 1000.0;
+  out->shader_mhz = h[1] ? (double)h[0] / (double)h[1] * out->rtc_mhz : 0.0;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out) {
+  if (!ctx || !out) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long h[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpy(h, ctx->d_diag + 4, 16, hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemset(ctx->d_diag + 4, 0, 16));
   out->shader_cycles = h[0];
   out->rtc_ticks = h[1];
   out->rtc_mhz = ctx->rtc_khz / 1000.0;

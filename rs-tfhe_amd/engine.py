@@ -465,6 +465,13 @@ class Engine:
         return {"shader_mhz": cs.shader_mhz, "rtc_mhz": cs.rtc_mhz, "shader_cycles": int(cs.shader_cycles),
                 "rtc_ticks": int(cs.rtc_ticks)}
 
+    def key_switch_clock_sample(self) -> dict:
+        """The same sample for the matrix-core key switch (k_key_switch_mfma)."""
+        cs = _capi.ClockSample()
+        self._chk(self._lib.tfhe_hip_get_key_switch_clock_sample(self._ctx, C.byref(cs)))
+        return {"shader_mhz": cs.shader_mhz, "rtc_mhz": cs.rtc_mhz, "shader_cycles": int(cs.shader_cycles),
+                "rtc_ticks": int(cs.rtc_ticks)}
+
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))
 

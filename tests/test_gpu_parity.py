@@ -184,10 +184,10 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_128_BIT", {}),                                # k_key_switch_b4 (LDS ring, base 4)
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_B4": "0"}),           # k_key_switch (generic, buffer loads)
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_SLICED": "2"}),       # k_key_switch_sliced forced at base 4
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<11> (int8 matrix cores), t = 9
-    ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<10>, t = 8
-    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<9>, t = 7
-    ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<11>, t = 8
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<6> (int8 matrix cores), t = 9, blocks of 6,6,5,5 tiles
+    ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
+    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
+    ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<6>, t = 8
     ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32)
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
     ("SECURITY_UINT2", {}),                                  # base 16
