@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 cd "$R/rs-tfhe_amd/csrc"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-function $flags \
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-function -DTFHE_EXPERIMENT $flags \
       -Rpass-analysis=kernel-resource-usage -shared -o ../libtfhe_v_$name.so tfhe_hip.hip 2>&1 \
       | grep -A8 "k_blind_rotateILi3ELb1E" | grep -E "VGPRs:|ScratchSize|SGPRs:" | tr '\n' ' ' | sed "s/^/$name: /"; echo ) &
 done

@@ -137,6 +137,11 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        # a library built with the timing-only ablation switches (csrc/experiment.hpp) computes wrong results by
+        # construction: only the experiment harnesses under profiles/exp/ may load it, and they say so
+        if b"EXPERIMENT" in handle.tfhe_hip_name() and os.environ.get("TFHE_HIP_ALLOW_EXPERIMENT") != "1":
+            raise ImportError(f"{LIB_PATH} is an ablated experiment build (results wrong by construction); "
+                              "set TFHE_HIP_ALLOW_EXPERIMENT=1 only for timing runs under profiles/exp/")
         _lib = handle
     return _lib
 

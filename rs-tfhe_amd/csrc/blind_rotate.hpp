@@ -38,9 +38,7 @@ __device__ __forceinline__ uint32_t rot_read(const P *p, int j, int k) {
 using f64x2 = __attribute__((ext_vector_type(2))) double;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 
-#ifndef TFHE_ABL_NOKEY  // timing-only ablation (results wrong by construction): no key loads
-#define TFHE_ABL_NOKEY 0
-#endif
+// (TFHE_ABL_NOKEY: timing-only experiment switch, see experiment.hpp -- 0 in every product build)
 __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lane_off, uint32_t soff) {
   if (TFHE_ABL_NOKEY) {
     f64x2 r;

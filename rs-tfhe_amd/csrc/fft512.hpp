@@ -40,6 +40,8 @@
 #endif
 #include <stdint.h>
 
+#include "experiment.hpp"
+
 namespace tfhe {
 
 constexpr int kN = 1024;
@@ -115,11 +117,7 @@ struct Twiddles {
 // Plain in-register 8-point DFT (no pre-twiddle).  INV=false: W8 = exp(-2*pi*i/8); INV=true: conjugate.
 // The two 1/sqrt2 twiddles are not applied where they arise: their common factor H is
 // carried to the last stage and folded into its add/sub as FMAs (X = b +- H*q).  52 instructions.
-// Timing-only ablation (results wrong by construction): TFHE_ABL_NOFFT removes the butterflies (the data
-// still makes every LDS round trip and meets every key word).
-#ifndef TFHE_ABL_NOFFT
-#define TFHE_ABL_NOFFT 0
-#endif
+// (TFHE_ABL_NOFFT: timing-only experiment switch, see experiment.hpp -- 0 in every product build)
 template <bool INV>
 __device__ __forceinline__ void dft8(double (&re)[8], double (&im)[8]) {
   if (TFHE_ABL_NOFFT) return;
@@ -255,19 +253,12 @@ __device__ __forceinline__ void wave_lds_order() { asm volatile("" ::: "memory")
 // c1*W8 = exp(-3*i*pi/16)
 constexpr double kP1c4 = 0.70710678118654752440084436210485;
 
-// Timing-only ablation (results wrong by construction): TFHE_ABL_NOLDS removes the transposes.
-#ifndef TFHE_ABL_NOLDS
-#define TFHE_ABL_NOLDS 0
-#endif
-// Timing-only ablation (results wrong by construction): TFHE_ABL_TPB_DPP replaces the LDS round trip of
-// transpose B (the exchange inside 8-lane groups) by the instruction mix a cross-lane version would issue --
-// three exchange stages over the 32 dwords a lane holds: lane bit 5 by 16 v_permlane32_swap, lane bit 4 by
-// 16 v_permlane16_swap, lane bit 3 by 48 DPP moves (row_ror:8 under bank masks needs a temporary per pair).
-// It answers "would DPP / permlane transposes be faster than LDS ones?" without building the re-indexed FFT.
-#ifndef TFHE_ABL_TPB_DPP
-#define TFHE_ABL_TPB_DPP 0
-#endif
-#ifndef TFHE_FFT_HOST_EMU
+// Timing-only experiment switches (experiment.hpp; 0 in every product build): TFHE_ABL_NOLDS removes the
+// transposes; TFHE_ABL_TPB_DPP replaces the LDS round trip of transpose B (the exchange inside 8-lane groups) by
+// the instruction mix a cross-lane version would issue -- lane bit 5 by 16 v_permlane32_swap, lane bit 4 by 16
+// v_permlane16_swap, lane bit 3 by 48 DPP moves.  It answered "would DPP / permlane transposes be faster than
+// LDS ones?" without building the re-indexed FFT (no: 331.5 vs 329.9 ms).
+#if !defined(TFHE_FFT_HOST_EMU) && TFHE_ABL_TPB_DPP
 __device__ __forceinline__ void abl_crosslane_exchange(double (&re)[8], double (&im)[8]) {
   uint32_t w[32];
 #pragma unroll
@@ -322,11 +313,9 @@ __device__ __forceinline__ void tpB_write(const double (&re)[8], const double (&
 }
 __device__ __forceinline__ void tpB_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
   if (TFHE_ABL_NOLDS) return;
-#ifndef TFHE_FFT_HOST_EMU
-  if (TFHE_ABL_TPB_DPP) {
-    abl_crosslane_exchange(re, im);
-    return;
-  }
+#if !defined(TFHE_FFT_HOST_EMU) && TFHE_ABL_TPB_DPP
+  abl_crosslane_exchange(re, im);
+  return;
 #endif
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll
@@ -345,11 +334,9 @@ __device__ __forceinline__ void tpBi_write(const double (&re)[8], const double (
 }
 __device__ __forceinline__ void tpBi_read(double (&re)[8], double (&im)[8], const double2 *tile, int lane) {
   if (TFHE_ABL_NOLDS) return;
-#ifndef TFHE_FFT_HOST_EMU
-  if (TFHE_ABL_TPB_DPP) {
-    abl_crosslane_exchange(re, im);
-    return;
-  }
+#if !defined(TFHE_FFT_HOST_EMU) && TFHE_ABL_TPB_DPP
+  abl_crosslane_exchange(re, im);
+  return;
 #endif
   const int hi = lane >> 3, lo = lane & 7;
 #pragma unroll

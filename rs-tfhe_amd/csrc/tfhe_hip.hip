@@ -552,7 +552,7 @@ T *pinned_view(T *p) {
 // =============================================================================
 extern "C" {
 
-const char *tfhe_hip_name(void) { return "hip-gfx950"; }
+const char *tfhe_hip_name(void) { return TFHE_ABLATED ? "hip-gfx950-EXPERIMENT" : "hip-gfx950"; }
 
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
