@@ -150,3 +150,54 @@ def test_reference_spqlios_external_product(O, keys128):
             for c in range(2):
                 swapped[c] += O.ref_poly_mul(ck.bootstrapping_key_time[i][(r + P.l) % (2 * P.l)][c], dec[r])
         assert signed_diff(swapped, exact) > (1 << 20)
+
+
+def test_reference_spqlios_pins_rotation_and_cmux(O, keys128):
+    """Direction of rotation, the `Torus::MAX - x` quirk (Q1) and one chained CMUX step held to REAL reference
+    arithmetic instead of a second restatement.
+
+    poly_mul_with_x_k (trgsw.rs:307-330) claims to be multiplication by X^k in Z[X]/(X^N+1), k in [0, 2N].
+    The reference's compiled SPQLIOS product with the monomial X^k mod (X^N+1) (= +X^k for k < N, -X^(k-N) for
+    N <= k < 2N, +1 at k = 2N) gives the true product; the quirk makes every WRAPPED coefficient
+    MAX - a = -a - 1 instead of -a.  So: equal on unwrapped coefficients, off by exactly one on wrapped ones --
+    which pins which side wraps (direction) and the off-by-one itself.  SPQLIOS truncates (+-1 LSB per product,
+    fft_processor_spqlios.cpp:128-129), so `a` holds multiples of 256: the reference product, rounded to the nearest
+    multiple of 256, is then the exact product, and an off-by-one stands out unambiguously."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    rng = np.random.default_rng(31)
+    a = (rng.integers(0, 2**20, N, dtype=np.uint64) * 256).astype(np.uint32)
+    for k in (0, 1, 2, N - 1, N, N + 1, 2 * N - 1, 2 * N):
+        mono = np.zeros(N, np.uint32)
+        kk = k % (2 * N)
+        if kk < N:
+            mono[kk] = 1
+        else:
+            mono[kk - N] = 0xFFFFFFFF  # -X^(k-N)
+        raw = O.ref_poly_mul(a, mono)
+        true = ((raw.astype(np.uint64) + 128) // 256 * 256).astype(np.uint32)  # exact product (wraps mod 2^32)
+        assert signed_diff(raw, true) <= 1
+        got = O.poly_mul_with_x_k(a, k)
+        # wrapped coefficients: output index j came from a[j - k + N] negated (k < N), or the complement region (k >= N)
+        j = np.arange(N)
+        wrapped = (j < k) if k < N else (j >= k - N)
+        if k == 2 * N:
+            wrapped = np.zeros(N, bool)
+        assert np.array_equal(got[~wrapped], true[~wrapped]), k
+        assert np.array_equal(got[wrapped], true[wrapped] - np.uint32(1)), k  # MAX - a = -a - 1 (Q1)
+    # one CMUX step (trgsw.rs:174-196) chained from reference products: in1 + ExtProd(BSK[i], X^k*in1 - in1),
+    # the external product assembled from Spqlios_poly_mul_1024 calls as in the test above
+    sk, ck = keys128
+    P = ck.params
+    acc = rng.integers(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
+    for i, k in ((3, 1), (500, N + 17), (699, 2 * N - 1)):
+        rot = np.stack([O.poly_mul_with_x_k(acc[0], k), O.poly_mul_with_x_k(acc[1], k)])
+        dec = O.decomposition(rot - acc, P.l, P.bgbit, ck.decomposition_offset)
+        ext = np.zeros((2, N), np.uint32)
+        for r in range(2 * P.l):
+            for c in range(2):
+                ext[c] += O.ref_poly_mul(ck.bootstrapping_key_time[i][r][c], dec[r])
+        ref_cmux = acc + ext
+        got = O.cmux(acc, rot, ck.bootstrapping_key[i], P.l, P.bgbit, ck.decomposition_offset)
+        assert signed_diff(got, ref_cmux) <= 2 * P.l  # SPQLIOS truncation, one LSB per product
+        acc = got  # chain
