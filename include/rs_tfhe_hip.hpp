@@ -128,13 +128,23 @@ inline TRLWELv1 gen_testvec() {
   return tv;
 }
 
-// ---- engine handle: C-ABI contexts per (parameter set, device), each holding one cloud key ----------
+// ---- engine handle: ONE C-ABI context per (parameter set, device); every cloud key is a key view of it ------
 // The reference passes `&CloudKey` into every call and its strategies are `Send + Sync`
-// (bootstrap/mod.rs:23); a C-ABI context holds ONE key at a time.  So (1) choosing the key and running under
-// it is one critical section (with_key), never "ensure, then call" -- another thread could swap the key in
-// between -- and (2) up to kMaxResidentKeys contexts per (parameter set, device) keep as many keys resident,
-// so threads alternating between a few keys neither wait on each other nor re-upload 172 MB per call.
+// (bootstrap/mod.rs:23).  The C ABI's answer is the KEY VIEW (tfhe_hip_key_create, include/tfhe_hip.h): another
+// resident cloud key on the same context -- same device, streams, scratch and mutex -- that every entry point
+// accepts in place of the context.  A call names its key by the handle it passes, so two threads with two keys
+// share one context and can never compute under each other's key.  Up to kMaxResidentKeys views stay resident
+// per (parameter set, device); beyond that the least recently used idle one is destroyed.
 class Engine {
+  struct View {
+    tfhe_hip_ctx *h = nullptr;
+    const CloudKey *key = nullptr;  // `&CloudKey` identity, as the reference borrows it ...
+    uint64_t fp = 0;                // ... plus a content sample: an address can be reused by a different key
+    uint64_t last_use = 0;
+    int users = 0;  // calls in flight (registry lock): never evicted while > 0
+    std::mutex load_mu;
+  };
+
  public:
   static constexpr size_t kMaxResidentKeys = 4;
   Engine(const SecurityParams &p, int device) : params_(p), device_(device) {
@@ -142,85 +152,111 @@ class Engine {
     int rc = tfhe_hip_ctx_create(&cp, device, &ctx_);
     if (rc != TFHE_HIP_OK) throw std::runtime_error(std::string("tfhe_hip_ctx_create: ") + tfhe_hip_last_error(nullptr));
   }
-  ~Engine() { tfhe_hip_ctx_destroy(ctx_); }
+  ~Engine() {
+    for (auto &v : views_) tfhe_hip_ctx_destroy(v->h);  // views before their context
+    tfhe_hip_ctx_destroy(ctx_);
+  }
   Engine(const Engine &) = delete;
   Engine &operator=(const Engine &) = delete;
 
-  // Run `call(ctx)` (one of the tfhe_hip_batch_* entry points; returns its status) with `ck` current.
-  template <class F>
-  void with_key(const CloudKey &ck, F &&call) {
-    std::lock_guard<std::mutex> lk(mu_);
-    ensure_key_locked(ck);
-    check(call(ctx_));
-  }
-  // Run `call(ctx)` under the engine lock without touching the key (key generation, stage entry points).
+  // A key view held for the duration of one or more calls (RAII: the view cannot be evicted meanwhile).
+  class Bound {
+   public:
+    Bound(Engine *e, View *v) : e_(e), v_(v) {}
+    Bound(Bound &&o) noexcept : e_(o.e_), v_(o.v_) { o.v_ = nullptr; }
+    Bound(const Bound &) = delete;
+    ~Bound() {
+      if (!v_) return;
+      std::lock_guard<std::mutex> lk(registry_mu());
+      --v_->users;
+    }
+    // Run `call(handle)` (one of the tfhe_hip_batch_* entry points; returns its status) under this view's key.
+    template <class F>
+    void with_key(const CloudKey &, F &&call) {
+      e_->check(call(v_->h));
+    }
+    tfhe_hip_ctx *handle() const { return v_->h; }
+    tfhe_hip_ctx *context() const { return e_->ctx_; }
+
+   private:
+    Engine *e_;
+    View *v_;
+  };
+
+  // Run `call(ctx)` on the context itself (stage entry points that need no key; the library serialises).
   template <class F>
   void locked(F &&call) {
-    std::lock_guard<std::mutex> lk(mu_);
     check(call(ctx_));
-  }
-  // the context now holds a key that no CloudKey object describes (tfhe_hip_gen_cloud_key*)
-  void forget_key() {
-    std::lock_guard<std::mutex> lk(mu_);
-    loaded_ = nullptr;
-    loaded_fp_ = 0;
   }
   void check(int rc) const {
     if (rc != TFHE_HIP_OK) throw std::runtime_error(std::string("tfhe_hip: ") + tfhe_hip_last_error(ctx_));
   }
   tfhe_hip_ctx *ctx() const { return ctx_; }
   const SecurityParams &params() const { return params_; }
+  size_t resident_keys() const {
+    std::lock_guard<std::mutex> lk(registry_mu());
+    return views_.size();
+  }
 
-  // first engine of (parameter set, device): key generation and the stage entry points
+  // THE engine of (parameter set, device)
   static Engine &for_params(const SecurityParams &p, int device = 0) {
     std::lock_guard<std::mutex> lk(registry_mu());
+    return for_params_locked(p, device);
+  }
+  // the key view that holds `ck` (by address and content sample) on the one context of its parameter set and
+  // device: found, or created (dropping the least recently used idle view beyond kMaxResidentKeys) and loaded
+  static Bound for_key(const CloudKey &ck, int device = 0) {
+    const uint64_t fp = fingerprint(ck);
+    Engine *e;
+    View *v = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(registry_mu());
+      e = &for_params_locked(ck.params, device);
+      for (auto &c : e->views_)
+        if (c->key == &ck && c->fp == fp) v = c.get();
+      if (!v) {
+        while (e->views_.size() >= kMaxResidentKeys) {
+          size_t victim = e->views_.size();
+          for (size_t i = 0; i < e->views_.size(); ++i)
+            if (e->views_[i]->users == 0 && (victim == e->views_.size() || e->views_[i]->last_use < e->views_[victim]->last_use))
+              victim = i;
+          if (victim == e->views_.size()) break;  // every view is in use: exceed the cap for now
+          tfhe_hip_ctx_destroy(e->views_[victim]->h);
+          e->views_.erase(e->views_.begin() + (long)victim);
+        }
+        e->views_.emplace_back(new View());
+        v = e->views_.back().get();
+        if (tfhe_hip_key_create(e->ctx_, &v->h) != TFHE_HIP_OK) {
+          e->views_.pop_back();
+          throw std::runtime_error("tfhe_hip_key_create failed");
+        }
+        v->key = &ck;
+        v->fp = fp;
+      }
+      ++v->users;
+      v->last_use = ++tick();
+    }
+    Bound b(e, v);
+    if (!tfhe_hip_key_is_loaded(v->h)) {
+      std::lock_guard<std::mutex> lk(v->load_mu);  // two threads meeting on a fresh view: one uploads
+      if (!tfhe_hip_key_is_loaded(v->h)) {
+        const SecurityParams &p = ck.params;
+        if (ck.bootstrapping_key.size() != (size_t)p.n * 2 * p.l * 2 * N ||
+            ck.key_switching_key.size() != N * (size_t)p.iks_t * p.base() * (p.n + 1))
+          throw std::runtime_error("CloudKey does not match the parameter set");
+        e->check(tfhe_hip_load_cloud_key(v->h, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
+                                         ck.decomposition_offset, ck.blind_rotate_testvec.a.data()));
+      }
+    }
+    return b;
+  }
+
+ private:
+  static Engine &for_params_locked(const SecurityParams &p, int device) {
     for (auto &e : registry())
       if (e->params_ == p && e->device_ == device) return *e;
     registry().emplace_back(new Engine(p, device));
     return *registry().back();
-  }
-  // the engine that holds `ck` (by address and content sample), else an empty one, else a new one up to
-  // kMaxResidentKeys per (parameter set, device), else the least recently used
-  static Engine &for_key(const CloudKey &ck, int device = 0) {
-    const uint64_t fp = fingerprint(ck);
-    std::lock_guard<std::mutex> lk(registry_mu());
-    Engine *empty = nullptr, *lru = nullptr;
-    size_t mine = 0;
-    for (auto &e : registry()) {
-      if (!(e->params_ == ck.params) || e->device_ != device) continue;
-      ++mine;
-      const CloudKey *held = e->loaded_.load();
-      if (held == &ck && e->loaded_fp_.load() == fp) {
-        e->last_use_ = ++tick();
-        return *e;
-      }
-      if (!held && !empty) empty = e.get();
-      if (!lru || e->last_use_ < lru->last_use_) lru = e.get();
-    }
-    Engine *pick = empty;
-    if (!pick && mine < kMaxResidentKeys) {
-      registry().emplace_back(new Engine(ck.params, device));
-      pick = registry().back().get();
-    }
-    if (!pick) pick = lru;
-    pick->last_use_ = ++tick();
-    return *pick;
-  }
-
- private:
-  void ensure_key_locked(const CloudKey &ck) {
-    // `&CloudKey` identity, as the reference borrows it -- plus a content sample, because an address
-    // can be reused by a different key once the first one is gone
-    const uint64_t fp = fingerprint(ck);
-    if (loaded_.load() == &ck && loaded_fp_.load() == fp) return;
-    const SecurityParams &p = params_;
-    if (ck.bootstrapping_key.size() != (size_t)p.n * 2 * p.l * 2 * N ||
-        ck.key_switching_key.size() != N * (size_t)p.iks_t * p.base() * (p.n + 1))
-      throw std::runtime_error("CloudKey does not match the parameter set");
-    check(tfhe_hip_load_cloud_key(ctx_, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
-                                  ck.decomposition_offset, ck.blind_rotate_testvec.a.data()));
-    loaded_ = &ck;
-    loaded_fp_ = fp;
   }
   static std::mutex &registry_mu() {
     static std::mutex m;
@@ -250,11 +286,8 @@ class Engine {
   }
   SecurityParams params_;
   tfhe_hip_ctx *ctx_ = nullptr;
-  std::atomic<const CloudKey *> loaded_{nullptr};  // written under mu_, read by for_key under the registry lock
-  std::atomic<uint64_t> loaded_fp_{0};
-  uint64_t last_use_ = 0;  // registry lock
+  std::vector<std::unique_ptr<View>> views_;  // registry lock
   int device_ = 0;
-  std::mutex mu_;
 };
 
 // ---- randomness: ChaCha20 (RFC 8439), the generator family of the reference's thread_rng --------------
@@ -405,13 +438,17 @@ inline CloudKey generate_cloud_key_with(const SecretKey &sk, int device, G &&gen
   ck.params = p;
   ck.bootstrapping_key.resize((size_t)p.n * 2 * p.l * 2 * N);
   ck.key_switching_key.resize(N * (size_t)p.iks_t * p.base() * (p.n + 1));
-  e.forget_key();
-  e.locked([&](tfhe_hip_ctx *c) {
-    int rc = gen(c);
-    if (rc != TFHE_HIP_OK) return rc;
-    return tfhe_hip_export_cloud_key(c, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
-                                     &ck.decomposition_offset, ck.blind_rotate_testvec.a.data());
-  });
+  // generated in a key view of its own: no other call can see or disturb the key being made, and no
+  // "which key does the context hold" state exists to go stale
+  tfhe_hip_ctx *view = nullptr;
+  e.check(tfhe_hip_key_create(e.ctx(), &view));
+  int rc = gen(view);
+  if (rc == TFHE_HIP_OK)
+    rc = tfhe_hip_export_cloud_key(view, ck.bootstrapping_key.data(), ck.key_switching_key.data(),
+                                   &ck.decomposition_offset, ck.blind_rotate_testvec.a.data());
+  const std::string msg = rc == TFHE_HIP_OK ? std::string() : std::string(tfhe_hip_last_error(view));
+  tfhe_hip_ctx_destroy(view);
+  if (rc != TFHE_HIP_OK) throw std::runtime_error("tfhe_hip: " + msg);
   return ck;
 }
 }  // namespace detail
@@ -499,7 +536,7 @@ inline std::vector<Ciphertext> unflatten(const Torus *flat, size_t count, int n)
 }
 inline std::vector<Ciphertext> batch_gate(int gate, const std::vector<std::pair<Ciphertext, Ciphertext>> &inputs,
                                           const CloudKey &ck, int device = 0) {
-  Engine &e = Engine::for_key(ck, device);
+  Engine::Bound e = Engine::for_key(ck, device);
   const int n = ck.params.n;
   const size_t words = inputs.size() * (size_t)(n + 1);
   std::vector<Torus> fb0, fb1, fb2;

@@ -99,6 +99,23 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx);
  * ctx == NULL).  Never NULL. */
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx);
 
+/* ---- key views: several resident cloud keys on ONE context -----------------------------------------
+ * Replaces: the `&CloudKey` every call of the reference names (src/bootstrap/mod.rs:23-38, src/gates.rs:43-45;
+ * strategies and keys are Send + Sync).  A context holds one cloud key of its own; tfhe_hip_key_create adds
+ * another resident key to it and returns a KEY VIEW: a tfhe_hip_ctx handle that EVERY entry point of this header
+ * accepts in place of the context -- tfhe_hip_load_cloud_key / tfhe_hip_gen_cloud_key* / tfhe_hip_cloud_key_buffers
+ * + tfhe_hip_adopt_cloud_key fill the view's key, tfhe_hip_export_cloud_key reads it, every tfhe_hip_batch_* call
+ * evaluates under it -- while device, streams, scratch buffers, profiling state and the mutex are the parent's.
+ * So a call names its key by the handle it passes; calls under different keys of one context may come from
+ * different threads (they serialise on the parent like any two calls on one context) and cost no second set of
+ * scratch buffers, streams or twiddle tables.  tfhe_hip_ctx_destroy(view) drains the parent's queued work and
+ * frees only the view's key; destroy every view before its parent.  tfhe_hip_last_error(view) is the parent's. */
+int tfhe_hip_key_create(tfhe_hip_ctx *ctx, tfhe_hip_ctx **key_view);
+/* The context a key view runs on (the handle itself for a plain context). */
+tfhe_hip_ctx *tfhe_hip_key_parent(tfhe_hip_ctx *key_view);
+/* 1 when the handle's own key has been loaded / generated / adopted, else 0. */
+int tfhe_hip_key_is_loaded(tfhe_hip_ctx *ctx_or_view);
+
 /* "MI355X-native HIP (gfx950)" style identification: Bootstrap::name()
  * (src/bootstrap/mod.rs:37) of the strategy this library backs. */
 const char *tfhe_hip_name(void);
@@ -339,6 +356,9 @@ typedef struct tfhe_hip_pool tfhe_hip_pool;
 int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int ndev, tfhe_hip_pool **out);
 void tfhe_hip_pool_destroy(tfhe_hip_pool *pool);
 int tfhe_hip_pool_size(const tfhe_hip_pool *pool);
+/* A key view of a pool: one tfhe_hip_key_create view per member (same devices, streams and scratch), accepted by
+ * every tfhe_hip_pool_* entry point; tfhe_hip_pool_destroy(view) frees only its keys.  Destroy views first. */
+int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **key_view);
 /* A member context, BORROWED: valid until tfhe_hip_pool_destroy, never to be passed to tfhe_hip_ctx_destroy. */
 tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *pool, int member);
 /* Text of the last failed pool call ("device D: ..."), or of the last failed create when pool == NULL. */

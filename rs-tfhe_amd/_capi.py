@@ -55,6 +55,10 @@ SIGNATURES = {
     "tfhe_hip_ctx_destroy": (None, [_CTX]),
     "tfhe_hip_last_error": (C.c_char_p, [_CTX]),
     "tfhe_hip_name": (C.c_char_p, []),
+    "tfhe_hip_key_create": (C.c_int, [_CTX, C.POINTER(_CTX)]),
+    "tfhe_hip_key_parent": (_CTX, [_CTX]),
+    "tfhe_hip_key_is_loaded": (C.c_int, [_CTX]),
+    "tfhe_hip_pool_key_create": (C.c_int, [_CTX, C.POINTER(_CTX)]),
     "tfhe_hip_load_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_uint32, _P]),
     "tfhe_hip_gen_cloud_key": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double, C.c_uint64]),
     "tfhe_hip_gen_cloud_key_secure": (C.c_int, [_CTX, _P, _P, C.c_double, C.c_double]),

@@ -21,44 +21,65 @@ from .engine import COPY, Engine
 from .lut import Generator, LookupTable
 from .params import DEFAULT_SECURITY, SecurityParams
 
-_engines: dict = {}  # (params, device) -> [Engine, ...]
+_engines: dict = {}  # (params, device) -> Engine: ONE C-ABI context per parameter set and device
+_views: dict = {}  # (params, device) -> {id(cloud_key): key view}: the resident keys of that context
 _engines_mu = threading.Lock()
-MAX_ENGINES_PER_SET = 4  # resident cloud keys per (parameter set, device): 172 MB each at SECURITY_128_BIT
+MAX_RESIDENT_KEYS = 4  # key views kept per (parameter set, device): 172 MB each at SECURITY_128_BIT (+ 104 MB of byte planes)
 
 
 def engine_for(params: SecurityParams, device: int = 0) -> Engine:
-    """The first Engine (C-ABI context) of (parameter set, device) in this process."""
+    """THE Engine (C-ABI context) of (parameter set, device) in this process."""
     with _engines_mu:
-        pool = _engines.setdefault((params, device), [])
-        if not pool:
-            pool.append(Engine(params, device))
-        return pool[0]
+        eng = _engines.get((params, device))
+        if eng is None:
+            eng = _engines[(params, device)] = Engine(params, device)
+        return eng
+
+
+def adopt_view(cloud_key, view: Engine) -> None:
+    """Register a key view that already holds `cloud_key` (e.g. the one it was generated in): first use uploads nothing."""
+    with _engines_mu:
+        view._key = cloud_key
+        _views.setdefault((view.params, view.device), {})[id(cloud_key)] = view
 
 
 @contextlib.contextmanager
 def keyed_engine(cloud_key, device: int = 0):
-    """An Engine holding exactly `cloud_key`, locked for the duration of the `with` body.
+    """The key view of `cloud_key` on the one context of its (parameter set, device).
 
-    The reference passes `&CloudKey` into every call (bootstrap/mod.rs:23-38 is `Send + Sync`); a context holds
-    one key at a time, so choosing the key and launching under it must be ONE critical section -- two threads
-    with two keys would otherwise compute under each other's key.  Up to MAX_ENGINES_PER_SET keys stay resident
-    per (parameter set, device), so alternating between a few keys does not re-upload them; beyond that the
-    least recently used context takes the new key."""
+    The reference passes `&CloudKey` into every call (bootstrap/mod.rs:23-38, `Send + Sync`).  Here a key is a KEY
+    VIEW of the context (`tfhe_hip_key_create`, include/tfhe_hip.h): its own resident key, the context's device,
+    streams, scratch and mutex.  A call names its key by the handle it is made on, so two threads with two keys
+    share one context and cannot compute under each other's key; up to MAX_RESIDENT_KEYS views stay resident per
+    (parameter set, device), beyond that the least recently used idle view is dropped."""
     params = _params_of(cloud_key)
+    base = engine_for(params, device)
     with _engines_mu:
-        pool = _engines.setdefault((params, device), [])
-        eng = next((e for e in pool if e._key is cloud_key), None)
-        if eng is None:
-            eng = next((e for e in pool if e._key is None), None)
-        if eng is None and len(pool) < MAX_ENGINES_PER_SET:
-            eng = Engine(params, device)
-            pool.append(eng)
-        if eng is None:
-            eng = min(pool, key=lambda e: e._last_use)
-        eng._last_use = next(_ticks)
-    with eng.lock:
-        eng.ensure_key(cloud_key)
-        yield eng
+        views = _views.setdefault((params, device), {})
+        view = views.get(id(cloud_key))
+        if view is not None and view._key is not cloud_key:  # a recycled id(): not this key
+            view = None
+        fresh = view is None
+        if fresh:
+            idle = [k for k, v in views.items() if v._users == 0]
+            while len(views) >= MAX_RESIDENT_KEYS and idle:
+                victim = min(idle, key=lambda k: views[k]._last_use)
+                idle.remove(victim)
+                views.pop(victim).close()
+            view = base.new_key_view()
+            view._key = cloud_key  # held: the id cannot be recycled while the view lives
+            views[id(cloud_key)] = view
+        view._users += 1
+        view._last_use = next(_ticks)
+    try:
+        if fresh or not view._lib.tfhe_hip_key_is_loaded(view._ctx):
+            with view.lock:  # two threads meeting on a fresh view: one uploads
+                if not view._lib.tfhe_hip_key_is_loaded(view._ctx):
+                    view.load_cloud_key(cloud_key)
+        yield view
+    finally:
+        with _engines_mu:
+            view._users -= 1
 
 
 def _tick_counter():

@@ -135,14 +135,14 @@ class SecretKey:
 
     # ---- evaluation key ----------------------------------------------------------------------
     def cloud_key(self, seed=None, device: int = 0):
-        """CloudKey::new(&secret_key) (key.rs:59-66): generated on the GPU, left loaded in the shared engine for
-        `device`, and returned in the reference layouts.  seed=None: the generator key comes from the OS
-        (`tfhe_hip_gen_cloud_key_secure`); an integer seed gives a reproducible, guessable key (tests only)."""
-        from .bootstrap import engine_for
+        """CloudKey::new(&secret_key) (key.rs:59-66): generated on the GPU in a fresh key view of the shared context
+        for `device` (which stays resident as this key's view: first use uploads nothing), and returned in the
+        reference layouts.  seed=None: the generator key comes from the OS (`tfhe_hip_gen_cloud_key_secure`); an
+        integer seed gives a reproducible, guessable key (tests only)."""
+        from .bootstrap import adopt_view, engine_for
 
-        eng = engine_for(self.params, device)
-        with eng.lock:
-            eng.gen_cloud_key(self.key_lv0, self.key_lv1, seed)
-            ck = eng.export_cloud_key()
-            eng._key = ck  # the engine already holds exactly this key: no re-upload on first use
+        view = engine_for(self.params, device).new_key_view()
+        view.gen_cloud_key(self.key_lv0, self.key_lv1, seed)
+        ck = view.export_cloud_key()
+        adopt_view(ck, view)
         return ck

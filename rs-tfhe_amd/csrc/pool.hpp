@@ -31,35 +31,36 @@ int pool_fail(tfhe_hip_pool *p, int code, const std::string &msg) {
   return code;
 }
 
-// dst takes src's key (engine layouts), device to device.  Both contexts idle on entry.
+// dst takes src's key (engine layouts), device to device.  Either may be a key view; both idle on entry.
 int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
-  std::lock_guard<std::mutex> lk(dst->mu);
-  DeviceGuard dg(dst->device);
-  if (dg.err != hipSuccess) return fail(dst, TFHE_HIP_EHIP, std::string("hipSetDevice: ") + hipGetErrorString(dg.err));
-  if (dst->scratch_owned) HIPCHK(dst, hipStreamSynchronize(dst->scratch_owner));
-  HIPCHK(dst, hipStreamSynchronize(dst->stream));
-  dst->scratch_owned = false;
-  const tfhe_hip_params &P = dst->P;
+  const KeyState *from = &src->own;  // the key src OWNS (K is only bound during a call)
+  const int src_device = src->device;
+  tfhe_hip_ctx *ctx = dst;
+  ENTER(ctx);
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
+  const tfhe_hip_params &P = ctx->P;
   const size_t bsk_bytes = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
   const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
-  dst->key_loaded = false;
-  if (!dst->d_bsk) HIPCHK(dst, hipMalloc((void **)&dst->d_bsk, bsk_bytes));
-  if (!dst->d_ksk) HIPCHK(dst, hipMalloc((void **)&dst->d_ksk, ksk_bytes + 4096));
-  if (!dst->d_testvec) HIPCHK(dst, hipMalloc((void **)&dst->d_testvec, 2 * kN * 4));
-  HIPCHK(dst, hipMemcpyPeer(dst->d_bsk, dst->device, src->d_bsk, src->device, bsk_bytes));
-  HIPCHK(dst, hipMemcpyPeer(dst->d_ksk, dst->device, src->d_ksk, src->device, ksk_bytes));
-  HIPCHK(dst, hipMemcpyPeer(dst->d_testvec, dst->device, src->d_testvec, src->device, 2 * kN * 4));
-  HIPCHK(dst, hipDeviceSynchronize());
-  CHK(build_ksk_planes(dst));
-  dst->offset = src->offset;
-  dst->key_loaded = true;
+  ctx->K->key_loaded = false;
+  if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, bsk_bytes));
+  if (!ctx->K->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, ksk_bytes + 4096));
+  if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
+  HIPCHK(ctx, hipMemcpyPeer(ctx->K->d_bsk, ctx->device, from->d_bsk, src_device, bsk_bytes));
+  HIPCHK(ctx, hipMemcpyPeer(ctx->K->d_ksk, ctx->device, from->d_ksk, src_device, ksk_bytes));
+  HIPCHK(ctx, hipMemcpyPeer(ctx->K->d_testvec, ctx->device, from->d_testvec, src_device, 2 * kN * 4));
+  HIPCHK(ctx, hipDeviceSynchronize());
+  CHK(build_ksk_planes(ctx));
+  ctx->K->offset = from->offset;
+  ctx->K->key_loaded = true;
   return TFHE_HIP_OK;
 }
 
 int replicate_key(tfhe_hip_pool *p) {
   for (size_t i = 1; i < p->ctxs.size(); ++i) {
     const int rc = clone_key(p->ctxs[i], p->ctxs[0]);
-    if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(p->ctxs[i]->device) + ": " + p->ctxs[i]->err);
+    if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(p->ctxs[i]->device) + ": " + tfhe_hip_last_error(p->ctxs[i]));
   }
   return TFHE_HIP_OK;
 }
@@ -96,7 +97,7 @@ int pool_map(tfhe_hip_pool *p, size_t count, F &&run) {
   for (auto &t : th) t.join();
   for (int r = 0; r < world; ++r)
     if (rc[(size_t)r] != TFHE_HIP_OK)
-      return pool_fail(p, rc[(size_t)r], "device " + std::to_string(p->ctxs[(size_t)r]->device) + ": " + p->ctxs[(size_t)r]->err);
+      return pool_fail(p, rc[(size_t)r], "device " + std::to_string(p->ctxs[(size_t)r]->device) + ": " + tfhe_hip_last_error(p->ctxs[(size_t)r]));
   return TFHE_HIP_OK;
 }
 
@@ -130,6 +131,26 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
   delete p;
 }
 
+// A key view of a pool: one key view per member context (same devices, same streams and scratch, its own cloud key).
+int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **out) {
+  if (!out) return TFHE_HIP_EINVAL;
+  *out = nullptr;
+  if (!pool) return TFHE_HIP_EINVAL;
+  tfhe_hip_pool *v = new tfhe_hip_pool();
+  for (auto *c : pool->ctxs) {
+    tfhe_hip_ctx *kv = nullptr;
+    const int rc = tfhe_hip_key_create(c, &kv);
+    if (rc != TFHE_HIP_OK) {
+      for (auto *x : v->ctxs) tfhe_hip_ctx_destroy(x);
+      delete v;
+      return rc;
+    }
+    v->ctxs.push_back(kv);
+  }
+  *out = v;
+  return TFHE_HIP_OK;
+}
+
 int tfhe_hip_pool_size(const tfhe_hip_pool *p) { return p ? (int)p->ctxs.size() : 0; }
 
 tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
@@ -151,7 +172,7 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 #define POOL_FIRST(p, call)                                                                                        \
   do {                                                                                                             \
     const int rc_ = (call);                                                                                        \
-    if (rc_ != TFHE_HIP_OK) return pool_fail(p, rc_, "device " + std::to_string((p)->ctxs[0]->device) + ": " + (p)->ctxs[0]->err); \
+    if (rc_ != TFHE_HIP_OK) return pool_fail(p, rc_, "device " + std::to_string((p)->ctxs[0]->device) + ": " + tfhe_hip_last_error((p)->ctxs[0])); \
   } while (0)
 
 int tfhe_hip_pool_load_cloud_key(tfhe_hip_pool *p, const double *bsk, const uint32_t *ksk, uint32_t decomp_offset,
@@ -188,7 +209,7 @@ int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *p, int member, double *bsk, ui
   if (member < 0 || (size_t)member >= p->ctxs.size()) return pool_fail(p, TFHE_HIP_EINVAL, "no such pool member");
   tfhe_hip_ctx *c = p->ctxs[(size_t)member];
   const int rc = tfhe_hip_export_cloud_key(c, bsk, ksk, decomp_offset, testvec);
-  if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + c->err);
+  if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + tfhe_hip_last_error(c));
   return TFHE_HIP_OK;
 }
 

@@ -41,17 +41,26 @@ struct DevBuf {
 
 }  // namespace
 
-struct tfhe_hip_ctx {
-  tfhe_hip_params P{};
-  int device = 0;
-  hipStream_t stream = nullptr;
+// One resident cloud key in the engine layouts (src/key.rs:51-56).  A context owns one (`own`); every key view
+// created with tfhe_hip_key_create owns another and runs on its parent's device, stream, scratch and mutex.
+struct KeyState {
   double2 *d_bsk = nullptr;
   uint32_t *d_ksk = nullptr;
   unsigned char *d_ksk8 = nullptr;  // base-4 sets: the key as signed byte planes in MFMA fragment order (k_ksk_planes)
   uint32_t *d_testvec = nullptr;
-  double2 *d_tw = nullptr;
   uint32_t offset = 0;
   bool key_loaded = false;
+};
+
+struct tfhe_hip_ctx {
+  tfhe_hip_params P{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  KeyState own;
+  KeyState *K = &own;            // the key of the call in progress (bound by ENTER under the mutex)
+  tfhe_hip_ctx *parent = nullptr;  // non-null: this handle is a key view of `parent` (only P, own, parent are used)
+  int views = 0;                 // live key views of this context
+  double2 *d_tw = nullptr;
   DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out;  // scratch / host-API staging
   std::mutex mu;
   std::string err = "";
@@ -94,9 +103,21 @@ struct DeviceGuard {
 };
 }  // namespace
 
-// every entry point: serialise on the context, make its device current, restore the caller's on return
+// Every entry point: a key view runs on its parent -- `ctx` is re-pointed at the parent, whose mutex serialises the
+// call, whose device is made current (the caller's is put back on return) and whose key pointer K is bound to the
+// view's key for the duration of the call (RAII; a plain context binds its own).
+namespace {
+struct KeyBind {
+  tfhe_hip_ctx *c;
+  KeyBind(tfhe_hip_ctx *base, KeyState *k) : c(base) { c->K = k; }
+  ~KeyBind() { c->K = &c->own; }
+};
+}  // namespace
 #define ENTER(ctx)                                                                     \
+  tfhe_hip_ctx *self_ = (ctx);                                                         \
+  if (self_->parent) (ctx) = self_->parent;                                            \
   std::lock_guard<std::mutex> lk_((ctx)->mu);                                          \
+  KeyBind kb_((ctx), &self_->own);                                                     \
   DeviceGuard dg_((ctx)->device);                                                      \
   if (dg_.err != hipSuccess) {                                                         \
     (ctx)->err = std::string("hipSetDevice: ") + hipGetErrorString(dg_.err);           \
@@ -216,13 +237,13 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   A.cb = gp.cb;
   A.cconst = gp.cconst;
   A.gate_codes = gate_codes;
-  A.testvec = testvec ? testvec : ctx->d_testvec;
+  A.testvec = testvec ? testvec : ctx->K->d_testvec;
   A.per_ct_stride = (testvec && per_ct) ? (size_t)2 * kN : 0;
-  A.bsk = ctx->d_bsk;
+  A.bsk = ctx->K->d_bsk;
   A.tw = ctx->d_tw;
   A.n = ctx->P.n;
   A.bgbit = ctx->P.bgbit;
-  A.offset = ctx->offset;
+  A.offset = ctx->K->offset;
   A.out_trlwe = out_trlwe;
   A.out_lv1 = out_lv1;
   A.out_ext2 = out_ext2;
@@ -309,7 +330,7 @@ bool ks_mfma_possible(const tfhe_hip_ctx *ctx) {
   return ctx->P.basebit == 2 && ctx->P.t >= 6 && ctx->P.t <= 13 && ks_mfma_nt(ctx->P.n) != 0;
 }
 bool ks_mfma_wanted(const tfhe_hip_ctx *ctx, size_t count) {
-  if (!ctx->d_ksk8 || !ctx->ks_mfma) return false;
+  if (!ctx->K->d_ksk8 || !ctx->ks_mfma) return false;
   return ctx->ks_mfma > 1 || count >= ctx->ks_mfma_min;
 }
 // rows of a level-1 buffer the matrix-core kernel may read: whole 256-row workgroups
@@ -321,12 +342,12 @@ int build_ksk_planes(tfhe_hip_ctx *ctx) {
   const tfhe_hip_params &P = ctx->P;
   const int nt = ks_mfma_nt(P.n);
   const size_t bytes = ks_mfma_key_bytes(P.n, P.t);
-  if (!ctx->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk8, bytes + kKmKeyTailPad));
+  if (!ctx->K->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk8, bytes + kKmKeyTailPad));
   HIPCHK(ctx, hipFuncSetAttribute((const void *)km_kernel(nt), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)ks_mfma_lds_bytes(nt)));
   const size_t chunks = bytes / 16;
-  hipLaunchKernelGGL(k_ksk_planes, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ksk,
-                     ctx->d_ksk8, P.n, P.t, chunks);
+  hipLaunchKernelGGL(k_ksk_planes, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->K->d_ksk,
+                     ctx->K->d_ksk8, P.n, P.t, chunks);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_HIP_OK;
@@ -355,7 +376,7 @@ int launch_key_switch_mfma(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1
   const size_t lds = ks_mfma_lds_bytes(nt);
   const int tiles = ks_mfma_total_tiles(n);
   hipLaunchKernelGGL(kern, dim3((unsigned)rb, (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks), 4), dim3(64 * kKmWaves), lds, s, lv1,
-                     (const unsigned char *)ctx->d_ksk8, n, ctx->P.t, dst, count,
+                     (const unsigned char *)ctx->K->d_ksk8, n, ctx->P.t, dst, count,
                      ctx->profiling ? ctx->d_diag + 4 : nullptr);
   HIPCHK(ctx, hipGetLastError());
   if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
@@ -373,7 +394,7 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
     // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
     const size_t kb = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
     HIPCHK(ctx, hipMemsetAsync(out, 0, count * (size_t)(n + 1) * 4, s));
-    hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->d_ksk,
+    hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->K->d_ksk,
                        (uint32_t)kb, n, ctx->P.basebit, ctx->P.t, out);
     HIPCHK(ctx, hipGetLastError());
     CHK(record_end(ctx, s, ctx->ev_ks));
@@ -391,16 +412,16 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   if ((ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024) {
     dim3 sgrid((unsigned)((count + kKsSlCts - 1) / kKsSlCts), (unsigned)((n + 1 + 63) / 64));
     if (ks_sliced_stage(1 << ctx->P.basebit) == 8)
-      hipLaunchKernelGGL(k_key_switch_sliced<8>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+      hipLaunchKernelGGL(k_key_switch_sliced<8>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
                          ctx->P.basebit, ctx->P.t, out, count);
     else
-      hipLaunchKernelGGL(k_key_switch_sliced<16>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+      hipLaunchKernelGGL(k_key_switch_sliced<16>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
                          ctx->P.basebit, ctx->P.t, out, count);
   } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
-    hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->d_ksk, n,
+    hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
                        ctx->P.t, out, count);
   else
-    hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->d_ksk, (uint32_t)ksk_bytes,
+    hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->K->d_ksk, (uint32_t)ksk_bytes,
                        n, ctx->P.basebit, ctx->P.t, out, count);
   HIPCHK(ctx, hipGetLastError());
   CHK(record_end(ctx, s, ctx->ev_ks));
@@ -408,7 +429,7 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
 }
 
 int need_key(tfhe_hip_ctx *ctx) {
-  if (!ctx->key_loaded) return fail(ctx, TFHE_HIP_ENOKEY, "cloud key not loaded");
+  if (!ctx->K->key_loaded) return fail(ctx, TFHE_HIP_ENOKEY, "cloud key not loaded");
   return TFHE_HIP_OK;
 }
 
@@ -555,6 +576,7 @@ extern "C" {
 const char *tfhe_hip_name(void) { return TFHE_ABLATED ? "hip-gfx950-EXPERIMENT" : "hip-gfx950"; }
 
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
+  if (ctx && ctx->parent) ctx = ctx->parent;
   return ctx ? ctx->err.c_str() : g_create_error.c_str();
 }
 
@@ -625,8 +647,29 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   return TFHE_HIP_OK;
 }
 
+namespace {
+void free_key(KeyState &k) {
+  if (k.d_bsk) (void)hipFree(k.d_bsk);
+  if (k.d_ksk) (void)hipFree(k.d_ksk);
+  if (k.d_ksk8) (void)hipFree(k.d_ksk8);
+  if (k.d_testvec) (void)hipFree(k.d_testvec);
+  k = KeyState();
+}
+}  // namespace
+
 void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   if (!ctx) return;
+  if (ctx->parent) {  // a key view: drain the work that may still read its key, free the key, leave the parent alone
+    tfhe_hip_ctx *base = ctx->parent;
+    std::lock_guard<std::mutex> lk(base->mu);
+    DeviceGuard dg(base->device);
+    if (base->scratch_owned && base->scratch_owner != base->stream) (void)hipStreamSynchronize(base->scratch_owner);
+    if (base->stream) (void)hipStreamSynchronize(base->stream);
+    free_key(ctx->own);
+    --base->views;
+    delete ctx;
+    return;
+  }
   DeviceGuard dg(ctx->device);
   if (ctx->scratch_owned && ctx->scratch_owner != ctx->stream) (void)hipStreamSynchronize(ctx->scratch_owner);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -642,13 +685,35 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx, &ctx->ks_out};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
-  if (ctx->d_bsk) (void)hipFree(ctx->d_bsk);
-  if (ctx->d_ksk) (void)hipFree(ctx->d_ksk);
-  if (ctx->d_ksk8) (void)hipFree(ctx->d_ksk8);
-  if (ctx->d_testvec) (void)hipFree(ctx->d_testvec);
+  free_key(ctx->own);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+}
+
+// ---- key views: several resident cloud keys on ONE context ------------------------------------------------
+int tfhe_hip_key_create(tfhe_hip_ctx *ctx, tfhe_hip_ctx **out) {
+  if (!out) return TFHE_HIP_EINVAL;
+  *out = nullptr;
+  if (!ctx) return TFHE_HIP_EINVAL;
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;  // a view of a view is a view of the same context
+  std::lock_guard<std::mutex> lk(base->mu);
+  tfhe_hip_ctx *v = new tfhe_hip_ctx();
+  v->P = base->P;
+  v->device = base->device;
+  v->parent = base;
+  ++base->views;
+  *out = v;
+  return TFHE_HIP_OK;
+}
+
+tfhe_hip_ctx *tfhe_hip_key_parent(tfhe_hip_ctx *key) { return key ? (key->parent ? key->parent : key) : nullptr; }
+
+int tfhe_hip_key_is_loaded(tfhe_hip_ctx *ctx) {
+  if (!ctx) return 0;
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  std::lock_guard<std::mutex> lk(base->mu);
+  return ctx->own.key_loaded ? 1 : 0;
 }
 
 int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
@@ -666,17 +731,17 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   const size_t bsk_bytes = polys * kN * sizeof(double);
   const int base = 1 << P.basebit;
   const size_t ksk_words = (size_t)kN * P.t * base * (size_t)(P.n + 1);
-  ctx->key_loaded = false;
-  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bsk_bytes));
-  if (!ctx->d_ksk)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
-  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
+  ctx->K->key_loaded = false;
+  if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, bsk_bytes));
+  if (!ctx->K->d_ksk)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
+  if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
   // bootstrapping key: upload the reference layout, permute + scale on the device
   double *d_ref = nullptr;
   HIPCHK(ctx, hipMalloc((void **)&d_ref, bsk_bytes));
   hipError_t e = hipMemcpyAsync(d_ref, bsk, bsk_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_bsk_convert, dim3((unsigned)polys), dim3(512), 0, ctx->stream, d_ref, ctx->d_bsk, polys);
+    hipLaunchKernelGGL(k_bsk_convert, dim3((unsigned)polys), dim3(512), 0, ctx->stream, d_ref, ctx->K->d_bsk, polys);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -689,18 +754,18 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
     HIPCHK(ctx, hipMalloc((void **)&d_kref, ksk_words * 4));
     hipError_t e2 = hipMemcpyAsync(d_kref, ksk, ksk_words * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e2 == hipSuccess) {
-      hipLaunchKernelGGL(k_ksk_convert, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_kref, ctx->d_ksk, P.n, base, rows);
+      hipLaunchKernelGGL(k_ksk_convert, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_kref, ctx->K->d_ksk, P.n, base, rows);
       e2 = hipGetLastError();
     }
     if (e2 == hipSuccess) e2 = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_kref);
     if (e2 != hipSuccess) return fail(ctx, TFHE_HIP_EHIP, std::string("ksk upload: ") + hipGetErrorString(e2));
   }
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, testvec, 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->K->d_testvec, testvec, 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   CHK(build_ksk_planes(ctx));
-  ctx->offset = decomp_offset;
-  ctx->key_loaded = true;
+  ctx->K->offset = decomp_offset;
+  ctx->K->key_loaded = true;
   return TFHE_HIP_OK;
 }
 
@@ -718,11 +783,11 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   const tfhe_hip_params &P = ctx->P;
   const int base = 1 << P.basebit;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
-  ctx->key_loaded = false;
-  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, polys * kN * sizeof(double)));
-  if (!ctx->d_ksk)
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
-  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
+  ctx->K->key_loaded = false;
+  if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, polys * kN * sizeof(double)));
+  if (!ctx->K->d_ksk)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
+  if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
   CHK(to_dev(ctx, ctx->h_a, key_lv0, (size_t)P.n * 4));
   CHK(to_dev(ctx, ctx->h_b, key_lv1, (size_t)kN * 4));
   CHK(ensure(ctx, ctx->h_c, (size_t)kN2 * sizeof(double2)));
@@ -736,20 +801,20 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   const ChaChaKey *d_rk = (const ChaChaKey *)ctx->h_idx.p;
   const dim3 bgrid((unsigned)(P.n * 2 * P.l));
   switch (P.l) {
-    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
-    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
-    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
   }
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_gen_ksk, dim3((unsigned)((size_t)kN * P.t * base)), dim3(256), 0, ctx->stream, d_k0, d_k1,
-                     ctx->d_ksk, P.n, P.basebit, P.t, alpha_ksk, d_rk);
+                     ctx->K->d_ksk, P.n, P.basebit, P.t, alpha_ksk, d_rk);
   HIPCHK(ctx, hipGetLastError());
   // decomposition offset (key.rs:78-89) and test vector (key.rs:91-100)
   uint32_t off = 0;
   for (int i = 0; i < P.l; ++i) off += ((1u << P.bgbit) / 2) * (1u << (32 - (i + 1) * P.bgbit));
   std::vector<uint32_t> tv(2 * kN, 0u);
   for (int i = 0; i < kN; ++i) tv[kN + i] = 0x20000000u;  // f64_to_torus(0.125)
-  HIPCHK(ctx, hipMemcpyAsync(ctx->d_testvec, tv.data(), 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->K->d_testvec, tv.data(), 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
   // the secret keys and the spectrum of the ring key do not outlive the call on the device
   HIPCHK(ctx, hipMemsetAsync(ctx->h_a.p, 0, (size_t)P.n * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->h_b.p, 0, (size_t)kN * 4, ctx->stream));
@@ -757,8 +822,8 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   HIPCHK(ctx, hipMemsetAsync(ctx->h_idx.p, 0, sizeof(ChaChaKey), ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   CHK(build_ksk_planes(ctx));
-  ctx->offset = off;
-  ctx->key_loaded = true;
+  ctx->K->offset = off;
+  ctx->K->key_loaded = true;
   return TFHE_HIP_OK;
 }
 
@@ -808,8 +873,9 @@ int tfhe_hip_gen_cloud_key_secure(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, co
     const ssize_t r = getrandom(buf + got, sizeof(buf) - got, 0);
     if (r < 0) {
       if (errno == EINTR) continue;
-      std::lock_guard<std::mutex> lk(ctx->mu);
-      return fail(ctx, TFHE_HIP_EHIP, std::string("getrandom: ") + strerror(errno));
+      tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+      std::lock_guard<std::mutex> lk(base->mu);
+      return fail(base, TFHE_HIP_EHIP, std::string("getrandom: ") + strerror(errno));
     }
     got += (size_t)r;
   }
@@ -830,20 +896,20 @@ int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uin
   if (bsk) {
     const size_t polys = (size_t)P.n * 2 * P.l * 2;
     CHK(ensure(ctx, ctx->h_out, polys * kN * sizeof(double)));
-    hipLaunchKernelGGL(k_bsk_export, dim3((unsigned)polys), dim3(512), 0, ctx->stream, ctx->d_bsk, (double *)ctx->h_out.p, polys);
+    hipLaunchKernelGGL(k_bsk_export, dim3((unsigned)polys), dim3(512), 0, ctx->stream, ctx->K->d_bsk, (double *)ctx->h_out.p, polys);
     HIPCHK(ctx, hipGetLastError());
     CHK(to_host(ctx, bsk, ctx->h_out, polys * kN * sizeof(double)));
   }
   if (ksk) {
     const size_t rows = (size_t)kN * P.t * base;
     CHK(ensure(ctx, ctx->h_out, rows * (size_t)(P.n + 1) * 4));
-    hipLaunchKernelGGL(k_ksk_export, dim3((unsigned)rows), dim3(256), 0, ctx->stream, ctx->d_ksk, (uint32_t *)ctx->h_out.p, P.n, rows);
+    hipLaunchKernelGGL(k_ksk_export, dim3((unsigned)rows), dim3(256), 0, ctx->stream, ctx->K->d_ksk, (uint32_t *)ctx->h_out.p, P.n, rows);
     HIPCHK(ctx, hipGetLastError());
     CHK(to_host(ctx, ksk, ctx->h_out, rows * (size_t)(P.n + 1) * 4));
   }
-  if (decomp_offset) *decomp_offset = ctx->offset;
+  if (decomp_offset) *decomp_offset = ctx->K->offset;
   if (testvec) {
-    HIPCHK(ctx, hipMemcpyAsync(testvec, ctx->d_testvec, 2 * kN * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(testvec, ctx->K->d_testvec, 2 * kN * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return TFHE_HIP_OK;
@@ -856,29 +922,29 @@ int tfhe_hip_cloud_key_buffers(tfhe_hip_ctx *ctx, void **bsk, size_t *bsk_bytes,
   const tfhe_hip_params &P = ctx->P;
   const size_t bb = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
   const size_t kb = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
-  if (!ctx->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_bsk, bb));
-  if (!ctx->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->d_ksk, kb + 4096));
-  if (!ctx->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->d_testvec, 2 * kN * 4));
-  if (bsk) *bsk = ctx->d_bsk;
+  if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, bb));
+  if (!ctx->K->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, kb + 4096));
+  if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
+  if (bsk) *bsk = ctx->K->d_bsk;
   if (bsk_bytes) *bsk_bytes = bb;
-  if (ksk) *ksk = ctx->d_ksk;
+  if (ksk) *ksk = ctx->K->d_ksk;
   if (ksk_bytes) *ksk_bytes = kb;
-  if (testvec) *testvec = ctx->d_testvec;
+  if (testvec) *testvec = ctx->K->d_testvec;
   if (testvec_bytes) *testvec_bytes = 2 * kN * 4;
-  if (decomp_offset) *decomp_offset = ctx->offset;
+  if (decomp_offset) *decomp_offset = ctx->K->offset;
   return TFHE_HIP_OK;
 }
 
 int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
   if (!ctx) return TFHE_HIP_EINVAL;
   ENTER(ctx);
-  if (!ctx->d_bsk || !ctx->d_ksk || !ctx->d_testvec)
+  if (!ctx->K->d_bsk || !ctx->K->d_ksk || !ctx->K->d_testvec)
     return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_adopt_cloud_key before tfhe_hip_cloud_key_buffers");
   // whatever filled the buffers (a peer copy, an RCCL broadcast on another stream) must have finished
   HIPCHK(ctx, hipDeviceSynchronize());
   CHK(build_ksk_planes(ctx));
-  ctx->offset = decomp_offset;
-  ctx->key_loaded = true;
+  ctx->K->offset = decomp_offset;
+  ctx->K->key_loaded = true;
   return TFHE_HIP_OK;
 }
 
@@ -1175,8 +1241,8 @@ int tfhe_hip_batch_external_product(tfhe_hip_ctx *ctx, const uint32_t *trlwe_in,
   const int32_t *idx = (const int32_t *)ctx->h_idx.p;
   uint32_t *o = (uint32_t *)ctx->h_out.p;
   const uint32_t bsk_bytes = (uint32_t)((size_t)ctx->P.n * 2 * ctx->P.l * 2 * kN2 * 16);
-  hipLaunchKernelGGL(ep_kernel(ctx), grid, block, kStageLdsBytes, ctx->stream, in, idx, ctx->d_bsk, bsk_bytes, ctx->d_tw,
-                     ctx->P.bgbit, ctx->offset, o);
+  hipLaunchKernelGGL(ep_kernel(ctx), grid, block, kStageLdsBytes, ctx->stream, in, idx, ctx->K->d_bsk, bsk_bytes, ctx->d_tw,
+                     ctx->P.bgbit, ctx->K->offset, o);
   HIPCHK(ctx, hipGetLastError());
   return to_host(ctx, trlwe_out, ctx->h_out, bytes);
 }

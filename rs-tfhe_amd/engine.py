@@ -77,22 +77,41 @@ class Engine:
     """Owns a tfhe_hip_ctx.  Host arrays are numpy uint32; *_dev methods take
     torch CUDA tensors (int32 storage of the u32 words) and only enqueue work."""
 
-    def __init__(self, params: SecurityParams, device: int = 0):
+    def __init__(self, params: SecurityParams, device: int = 0, _view_of: "Engine" = None):
         self.params = params
         self.device = device
         self._lib = _capi.lib()
-        cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
         ctx = C.c_void_p()
-        rc = self._lib.tfhe_hip_ctx_create(C.byref(cp), device, C.byref(ctx))
-        if rc != _capi.OK:
-            msg = self._lib.tfhe_hip_last_error(None)
-            raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+        if _view_of is not None:  # a key view: another resident cloud key on the parent's context
+            rc = self._lib.tfhe_hip_key_create(_view_of._ctx, C.byref(ctx))
+            if rc != _capi.OK:
+                raise _capi.TfheHipError(rc, "tfhe_hip_key_create failed")
+        else:
+            cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
+            rc = self._lib.tfhe_hip_ctx_create(C.byref(cp), device, C.byref(ctx))
+            if rc != _capi.OK:
+                msg = self._lib.tfhe_hip_last_error(None)
+                raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._ctx = ctx
         self._owner = None  # a Pool when the context is borrowed from one (tfhe_hip_pool_ctx): never destroyed here
+        self._parent = _view_of  # keeps the parent context alive for as long as this view exists
+        self._views = []  # weak references to the live key views of this context (closed before it)
         self._key = None  # the CloudKey object currently loaded (held, so identity cannot be recycled)
-        # held by bootstrap.keyed_engine() across "make this key current" + the launch that needs it
-        self.lock = threading.RLock()
+        self.lock = threading.RLock()  # for callers that want several calls on this handle back to back
         self._last_use = 0
+        self._users = 0  # bootstrap.keyed_engine: calls in flight under this view (never evicted while > 0)
+        if _view_of is not None:
+            import weakref
+
+            _view_of._views.append(weakref.ref(self))
+
+    def new_key_view(self) -> "Engine":
+        """Another resident cloud key on this context (`tfhe_hip_key_create`): an Engine handle with its own key
+        that shares this context's device, streams, scratch buffers and mutex.  Every method works on it; calls
+        under different views may come from different threads.  Replaces the reference's `&CloudKey` argument
+        (src/bootstrap/mod.rs:23-38): a call names its key by the handle it is made on."""
+        base = self._parent if self._parent is not None else self
+        return Engine(base.params, base.device, _view_of=base)
 
     @classmethod
     def from_pool(cls, pool: "Pool", member: int) -> "Engine":
@@ -105,18 +124,27 @@ class Engine:
         self.params, self.device, self._lib = pool.params, pool.devices[member], pool._lib
         self._ctx = C.c_void_p(ctx)
         self._owner = pool
+        self._parent = None
+        self._views = []
         self._key = ("pool", object())
         self.lock = threading.RLock()
         self._last_use = 0
+        self._users = 0
         return self
 
     # -- lifetime -------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_ctx", None):
+            for ref in getattr(self, "_views", []):  # key views go before the context they run on
+                v = ref()
+                if v is not None:
+                    v.close()
+            self._views = []
             if getattr(self, "_owner", None) is None:
                 self._lib.tfhe_hip_ctx_destroy(self._ctx)
             self._ctx = None
             self._owner = None
+            self._parent = None
 
     def __del__(self):
         try:
@@ -482,23 +510,45 @@ class Pool:
     contexts on one GPU).  The cloud key goes to the first device once and is replicated device to device;
     every batch call splits its host arrays contiguously over the members and keeps input order."""
 
-    def __init__(self, params: SecurityParams, devices):
+    def __init__(self, params: SecurityParams, devices, _view_of: "Pool" = None):
         self.params = params
         self.devices = [int(d) for d in devices]
         self._lib = _capi.lib()
-        cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
-        arr = (C.c_int * len(self.devices))(*self.devices)
         h = C.c_void_p()
-        rc = self._lib.tfhe_hip_pool_create(C.byref(cp), arr, len(self.devices), C.byref(h))
-        if rc != _capi.OK:
-            msg = self._lib.tfhe_hip_pool_last_error(None)
-            raise _capi.TfheHipError(rc, msg.decode() if msg else "")
+        if _view_of is not None:  # a key view of a pool: one key view per member context
+            rc = self._lib.tfhe_hip_pool_key_create(_view_of._h, C.byref(h))
+            if rc != _capi.OK:
+                raise _capi.TfheHipError(rc, "tfhe_hip_pool_key_create failed")
+        else:
+            cp = _capi.Params(params.n, params.l, params.bgbit, params.basebit, params.iks_t)
+            arr = (C.c_int * len(self.devices))(*self.devices)
+            rc = self._lib.tfhe_hip_pool_create(C.byref(cp), arr, len(self.devices), C.byref(h))
+            if rc != _capi.OK:
+                msg = self._lib.tfhe_hip_pool_last_error(None)
+                raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._h = h
+        self._parent = _view_of  # keeps the parent pool alive for as long as this view exists
+        self._views = []
+        if _view_of is not None:
+            import weakref
+
+            _view_of._views.append(weakref.ref(self))
+
+    def new_key_view(self) -> "Pool":
+        """Another resident cloud key on every member of this pool (`tfhe_hip_pool_key_create`)."""
+        base = self._parent if self._parent is not None else self
+        return Pool(base.params, base.devices, _view_of=base)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
+            for ref in getattr(self, "_views", []):  # key views go before the pool they run on
+                v = ref()
+                if v is not None:
+                    v.close()
+            self._views = []
             self._lib.tfhe_hip_pool_destroy(self._h)
             self._h = None
+            self._parent = None
 
     def __del__(self):
         try:

@@ -208,7 +208,7 @@ int main() {
 
     // ---- two threads, two keys, alternating (bootstrap/mod.rs:23: strategies are Send + Sync and every call
     // names its &CloudKey): each thread must always compute under ITS key.  A shared context whose key is
-    // checked and then used in two steps fails this; with_key + one resident context per key passes it.
+    // checked and then used in two steps fails this; one key view per key on ONE context passes it.
     {
       rs_tfhe::SecretKey sk2 = rs_tfhe::SecretKey::generate(P, 999);
       CloudKey gk2 = generate_cloud_key_seeded(sk2, 78);
@@ -229,6 +229,12 @@ int main() {
       t1.join();
       t2.join();
       CHECK(bad.load() == 0, "two threads with two alternating keys: %d wrong results", bad.load());
+      // ... and they did it on ONE context: both keys are key views (tfhe_hip_key_create) of the same handle
+      Engine &base = Engine::for_params(P, 0);
+      auto b1 = Engine::for_key(gk), b2 = Engine::for_key(gk2);
+      CHECK(b1.context() == base.ctx() && b2.context() == base.ctx() && b1.handle() != b2.handle(), "one context, two key views");
+      CHECK(tfhe_hip_key_parent(b1.handle()) == base.ctx() && tfhe_hip_key_is_loaded(b2.handle()) == 1, "views of the shared context");
+      CHECK(base.resident_keys() >= 2 && base.resident_keys() <= Engine::kMaxResidentKeys, "resident key views: %zu", base.resident_keys());
     }
     // several devices behind one handle (here: two contexts on GPU 0): same words as the single-context path,
     // in input order, at a count that does not divide evenly

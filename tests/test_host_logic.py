@@ -222,51 +222,69 @@ def test_kernels_compile_without_scratch_and_keep_their_occupancy():
 
 
 def test_keyed_engine_pool_logic(monkeypatch):
-    """bootstrap.keyed_engine (host logic, no GPU): a key stays resident in the context that holds it, an empty
-    context is preferred over a new one, at most MAX_ENGINES_PER_SET contexts exist per (parameter set, device), the
-    least recently used one is recycled beyond that, and key choice + use happen under the context's lock."""
+    """bootstrap.keyed_engine (host logic, no GPU): ONE context per (parameter set, device); every cloud key gets a
+    key view of it that stays resident (no re-upload), at most MAX_RESIDENT_KEYS views are kept, the least recently
+    used IDLE one is dropped beyond that, and a view in use is never dropped."""
     import threading
 
     from rs_tfhe_amd import bootstrap as B
     from rs_tfhe_amd.params import SECURITY_128_BIT as P
 
-    created = []
+    contexts, views = [], []
+
+    class FakeLib:
+        @staticmethod
+        def tfhe_hip_key_is_loaded(ctx):
+            return int(ctx.loaded)
 
     class FakeEngine:
-        def __init__(self, params, device):
-            self.params, self.device = params, device
-            self._key, self._last_use, self.lock = None, 0, threading.RLock()
-            self.loads = 0
-            created.append(self)
+        def __init__(self, params, device, _view_of=None):
+            self.params, self.device, self._parent = params, device, _view_of
+            self._key, self._last_use, self._users, self.lock = None, 0, 0, threading.RLock()
+            self._lib, self._ctx = FakeLib, self
+            self.loaded, self.loads, self.closed = False, 0, False
+            (views if _view_of is not None else contexts).append(self)
 
-        def ensure_key(self, ck):
-            assert self.lock._is_owned()  # chosen and loaded inside one critical section
-            if self._key is not ck:
-                self._key = ck
-                self.loads += 1
+        def new_key_view(self):
+            return FakeEngine(self.params, self.device, _view_of=self)
+
+        def load_cloud_key(self, ck):
+            self._key, self.loaded = ck, True
+            self.loads += 1
+
+        def close(self):
+            self.closed = True
 
     class Key:
         params = P
 
     monkeypatch.setattr(B, "Engine", FakeEngine)
     monkeypatch.setattr(B, "_engines", {})
+    monkeypatch.setattr(B, "_views", {})
     keys = [Key() for _ in range(6)]
-    with B.keyed_engine(keys[0]) as e0:
-        assert e0._key is keys[0] and e0.lock._is_owned()
+    with B.keyed_engine(keys[0]) as v0:
+        assert v0._key is keys[0] and v0._parent is contexts[0] and v0._users == 1
+    assert v0._users == 0
     with B.keyed_engine(keys[0]) as again:
-        assert again is e0 and e0.loads == 1  # no re-upload
-    engines = []
+        assert again is v0 and v0.loads == 1  # no re-upload
+    held = []
     for k in keys[1:4]:
-        with B.keyed_engine(k) as e:
-            engines.append(e)
-    assert len(created) == B.MAX_ENGINES_PER_SET == 4 and len(set(map(id, [e0] + engines))) == 4
-    with B.keyed_engine(keys[0]):  # touch key 0: key 1's context is now the least recently used
+        with B.keyed_engine(k) as v:
+            held.append(v)
+    assert len(contexts) == 1 and len(views) == B.MAX_RESIDENT_KEYS == 4  # one context, four resident keys
+    with B.keyed_engine(keys[0]):  # touch key 0: key 1's view is now the least recently used
         pass
-    with B.keyed_engine(keys[4]) as e:
-        assert e is engines[0] and e._key is keys[4] and len(created) == 4  # recycled, not grown
-    with B.keyed_engine(keys[0]) as e:
-        assert e is e0 and e0.loads == 1  # still resident
-    # another device gets its own pool
-    with B.keyed_engine(keys[5], device=1) as e:
-        assert e.device == 1 and len(created) == 5
-    assert B.engine_for(P, 0) is e0
+    with B.keyed_engine(keys[4]) as v:
+        assert v._key is keys[4] and held[0].closed and not v0.closed and len(contexts) == 1
+    with B.keyed_engine(keys[0]) as v:
+        assert v is v0 and v0.loads == 1  # still resident
+    # a view in use is never the victim, whatever its age
+    with B.keyed_engine(keys[2]) as busy:
+        for k in (keys[1], keys[5], Key()):
+            with B.keyed_engine(k):
+                pass
+        assert not busy.closed
+    # another device gets its own context
+    with B.keyed_engine(keys[5], device=1) as v:
+        assert v.device == 1 and len(contexts) == 2
+    assert B.engine_for(P, 0) is contexts[0]
