@@ -425,6 +425,8 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
   constexpr int NT = 64 * W;
   const size_t ct = blockIdx.x;
   const int n = A.n;
+  const unsigned long long clk0 = A.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rtc0 = A.clk ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
   Twiddles tw;
   tw.load(A.tw, t2tab, lane);  // every wave stores the same 64 entries; ends with a workgroup barrier
@@ -480,8 +482,14 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
     vb[s] = ldkey(bsk_rsrc, lane_off, my_row + (uint32_t)(kN2 * 16 + s * 1024));
   }
 
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_LAT_STAMPS)  // per-phase cycle stamps of step n/2 (profiles/exp/latency.py --stamps)
+#define LAT_STAMP(q) do { if (A.clk && i == n / 2 && lane == 0 && blockIdx.x == 0) A.clk[8 + wave * 16 + (q)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LAT_STAMP(q) do { } while (0)
+#endif
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
+    LAT_STAMP(0);
     const int k = s_abar[i];
     const uint32_t *p = acc + half_sel * kN;
     double re[8], im[8];
@@ -493,8 +501,10 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
       re[m] = (double)sbfe(w_lo, shift, bgbit);
       im[m] = (double)sbfe(w_hi, shift, bgbit);
     }
+    LAT_STAMP(1);
     fft_forward(re, im, tw, mytile, lane);
     wave_lds_sync();  // the transform's last tile reads are done: the tile becomes the fa-partial slot
+    LAT_STAMP(2);
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       mytile[s * 64 + lane] = make_double2(re[s] * va[s].x - im[s] * va[s].y, re[s] * va[s].y + im[s] * va[s].x);
@@ -507,7 +517,9 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
       va[s] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)s * 1024u);
       vb[s] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)(kN2 * 16 + s * 1024));
     }
+    LAT_STAMP(3);
     __syncthreads();  // all 2L partial products of both spectra are in LDS
+    LAT_STAMP(4);
     if (wave < 2) {   // wave 0: a spectrum (tiles), wave 1: b spectrum (fbpart)
       const double2 *src = wave == 0 ? tiles : fbpart;
       const size_t stride = wave == 0 ? (size_t)kTileCplx : (size_t)kN2;
@@ -526,7 +538,9 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
           f_re[s] += v.x;
           f_im[s] += v.y;
         }
+      LAT_STAMP(5);
       fft_inverse(f_re, f_im, tw, tiles + (size_t)(W + wave) * kTileCplx, lane);
+      LAT_STAMP(6);
       uint32_t *q = acc + wave * kN;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
@@ -535,8 +549,11 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
         q[j + kN2] += round_to_torus<FAST>(f_im[m]);
       }
     }
+    LAT_STAMP(7);
     __syncthreads();  // the accumulator is final for this step; partial slots are free again
+    LAT_STAMP(8);
   }
+#undef LAT_STAMP
 
   if (A.out_trlwe) {
     uint32_t *o = A.out_trlwe + ct * (size_t)(2 * kN);
@@ -551,6 +568,10 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
     uint32_t *o = A.out_ext2 + ct * (size_t)(n + 1);
     for (int i = tid; i < n; i += NT) o[i] = i == 0 ? acc[0] : ~acc[n - i];
     if (tid == 0) o[n] = acc[kN];
+  }
+  if (A.clk && tid == 0) {
+    atomicAdd(&A.clk[0], __builtin_amdgcn_s_memtime() - clk0);
+    atomicAdd(&A.clk[1], __builtin_amdgcn_s_memrealtime() - rtc0);
   }
 }
 

@@ -121,6 +121,10 @@ int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int 
     }
     p->ctxs.push_back(c);
   }
+  // several members fed by one host: each stages its pageable shard through a pinned arena of its own (to_dev)
+  const char *env = getenv("TFHE_HIP_POOL_PINNED_STAGING");
+  const bool stage = env ? atoi(env) != 0 : ndev > 1;
+  for (auto *c : p->ctxs) c->stage_pinned = stage;
   *out = p;
   return TFHE_HIP_OK;
 }

@@ -38,6 +38,10 @@ struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
 };
+struct PinBuf {  // pinned host arena (hipHostMalloc)
+  void *p = nullptr;
+  size_t cap = 0;
+};
 
 }  // namespace
 
@@ -62,6 +66,8 @@ struct tfhe_hip_ctx {
   int views = 0;                 // live key views of this context
   double2 *d_tw = nullptr;
   DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out;  // scratch / host-API staging
+  PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
+  bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
   std::mutex mu;
   std::string err = "";
   bool profiling = false;
@@ -532,13 +538,46 @@ int mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, 
 }
 
 // host staging helpers
+// Pool members (several contexts fed from one host by one thread each) stage pageable operands through a pinned
+// arena of their own: the member's thread copies its slice with memcpy, the DMA engine takes it from there, and
+// no two members meet in the runtime's single pageable-copy staging path.  A lone context keeps the runtime's
+// pipelined pageable copy (one thread cannot memcpy 550 MB faster than that).
+int ensure_pinned(tfhe_hip_ctx *ctx, PinBuf &b, size_t bytes) {
+  if (bytes <= b.cap) return TFHE_HIP_OK;
+  if (b.p) HIPCHK(ctx, hipHostFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes + bytes / 4;
+  if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    b.p = nullptr;
+    return TFHE_HIP_ENOMEM;  // caller falls back to the pageable copy
+  }
+  b.cap = want;
+  return TFHE_HIP_OK;
+}
+
 int to_dev(tfhe_hip_ctx *ctx, DevBuf &b, const void *src, size_t bytes) {
   CHK(ensure(ctx, b, bytes));
+  if (ctx->stage_pinned && bytes >= (1u << 20)) {
+    PinBuf *pin = &b == &ctx->h_a ? &ctx->p_a : &b == &ctx->h_b ? &ctx->p_b : &b == &ctx->h_c ? &ctx->p_c : nullptr;
+    if (pin && ensure_pinned(ctx, *pin, bytes) == TFHE_HIP_OK) {
+      memcpy(pin->p, src, bytes);
+      HIPCHK(ctx, hipMemcpyAsync(b.p, pin->p, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return TFHE_HIP_OK;
+    }
+  }
   HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   return TFHE_HIP_OK;
 }
 
 int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
+  if (ctx->stage_pinned && bytes >= (1u << 20) && &b == &ctx->h_out && ensure_pinned(ctx, ctx->p_out, bytes) == TFHE_HIP_OK) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->p_out.p, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->p_out.p, bytes);
+    return TFHE_HIP_OK;
+  }
   HIPCHK(ctx, hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return TFHE_HIP_OK;
@@ -614,8 +653,8 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (dg.err != hipSuccess) return bail("hipSetDevice", dg.err);
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
     return bail("hipStreamCreate", e);
-  if ((e = hipMalloc((void **)&ctx->d_diag, 64)) != hipSuccess) return bail("hipMalloc diagnostics", e);
-  if ((e = hipMemset(ctx->d_diag, 0, 64)) != hipSuccess) return bail("hipMemset diagnostics", e);
+  if ((e = hipMalloc((void **)&ctx->d_diag, 1024)) != hipSuccess) return bail("hipMalloc diagnostics", e);
+  if ((e = hipMemset(ctx->d_diag, 0, 1024)) != hipSuccess) return bail("hipMemset diagnostics", e);
   if (hipDeviceGetAttribute(&ctx->rtc_khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || ctx->rtc_khz <= 0)
     ctx->rtc_khz = 100000;
   hipDeviceProp_t prop;
@@ -686,6 +725,8 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   free_key(ctx->own);
+  for (PinBuf *b : {&ctx->p_a, &ctx->p_b, &ctx->p_c, &ctx->p_out})
+    if (b->p) (void)hipHostFree(b->p);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1384,6 +1425,17 @@ int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sampl
   out->shader_mhz = h[1] ? (double)h[0] / (double)h[1] * out->rtc_mhz : 0.0;
   return TFHE_HIP_OK;
 }
+
+#ifdef TFHE_EXPERIMENT
+// experiment builds only (profiles/exp/): the raw diagnostics words, e.g. the per-phase stamps of TFHE_LAT_STAMPS
+extern "C" int tfhe_hip_experiment_diag(tfhe_hip_ctx *ctx, unsigned long long *out, size_t words) {
+  if (!ctx || !out || words > 128) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(out, ctx->d_diag, words * 8, hipMemcpyDeviceToHost));
+  return TFHE_HIP_OK;
+}
+#endif
 
 int tfhe_hip_host_alloc(size_t bytes, void **out) {
   if (!out) return TFHE_HIP_EINVAL;

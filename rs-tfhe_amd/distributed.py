@@ -110,34 +110,46 @@ def broadcast_cloud_key(cloud_key_or_none, params, src: int = 0):
                     fields["blind_rotate_testvec"])
 
 
-def broadcast_engine_key(engine, src: int = 0) -> None:
-    """Replicate the cloud key held by rank `src`'s engine into every other rank's engine, device to device:
-    the three key buffers are broadcast IN PLACE in the engine layouts (RCCL over xGMI under the "nccl" backend),
-    so nothing is converted twice and nothing passes through host memory."""
+def broadcast_engine_key(engine, src: int = 0, in_place: bool = None) -> None:
+    """Replicate the cloud key held by rank `src`'s engine into every other rank's engine in the engine layouts
+    (nothing is converted twice): RCCL broadcast over xGMI under the "nccl" backend, device to device.
+
+    The transport is chosen ONCE for all ranks, before the first collective (a per-rank fallback would leave the
+    ranks issuing different numbers of collectives): `in_place` (default: env TFHE_BCAST_INPLACE == "1") broadcasts
+    on the context's own buffers; otherwise -- the default -- each buffer goes through a tensor from torch's
+    allocator (one extra device-side copy of 172 MB, once per job), which every RCCL transport accepts.  Receivers
+    drain their engine first and hold no valid key until `adopt_cloud_key`."""
+    import os
+
     import torch
     import torch.distributed as dist
 
+    if in_place is None:
+        in_place = os.environ.get("TFHE_BCAST_INPLACE") == "1"
+    rank = dist.get_rank()
+    if rank != src:
+        engine.synchronize()  # nothing queued on this engine may still read the buffers about to be overwritten
     bsk, ksk, tv, off = engine.cloud_key_device_tensors()
     offt = torch.tensor([off], dtype=torch.int64, device=bsk.device)
     if dist.get_backend() == "nccl":
         for t in (bsk, ksk, tv, offt):
-            try:
-                dist.broadcast(t, src=src)  # in place, on the context's own buffer
-            except RuntimeError:
-                # a transport that insists on memory from torch's allocator: one device-side staging copy
-                st = t.clone()
+            if in_place:
+                dist.broadcast(t, src=src)  # on the context's own buffer
+            else:
+                st = t.clone() if rank == src else torch.empty_like(t)
                 dist.broadcast(st, src=src)
-                if dist.get_rank() != src:
+                if rank != src:
                     t.copy_(st)
+                del st
     else:  # gloo moves host memory: stage (plumbing tests on boxes with fewer GPUs than ranks)
         for t in (bsk, ksk, tv, offt):
             h = t.cpu()
             dist.broadcast(h, src=src)
-            if dist.get_rank() != src:
+            if rank != src:
                 t.copy_(h)
     if bsk.is_cuda:
         torch.cuda.synchronize(bsk.device)
-    if dist.get_rank() != src:
+    if rank != src:
         engine.adopt_cloud_key(int(offt.item()))
 
 

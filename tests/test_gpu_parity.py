@@ -1455,3 +1455,51 @@ def test_one_context_from_several_threads(O, eng128, keys128):
     assert not errors
     for (gate, A, B, ca, cb), got in zip(jobs, results):
         assert np.array_equal(got, O.batch_gate(ck, gate, ca, cb))
+
+
+# ---- the N > 1 paths of bench.py, run here so that their first execution is not the driver's 8-GPU box ----------
+def _run_bench(extra_args, env_extra, timeout=900):
+    """bench.py as a FRESH child process (its own HIP runtime), the one JSON line it prints."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    env.setdefault("MASTER_PORT", "29547")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`bench.py --gpus 2` end to end with two ranks on this box's one GPU (BENCH_SHARE_GPU=1: rendezvous over gloo,
+    since RCCL refuses two ranks per device): torchrun child, key generated on rank 0 and broadcast in the engine
+    layouts, every rank bootstraps its own shard, barrier + max-over-ranks timing, rank 0 prints the line."""
+    d = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2048", "--no-cpu-baseline"],
+                   {"BENCH_SHARE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["decrypt_ok"] is True and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 4096 and d["value"] > 0 and d["unit"] == "bootstraps/s"
+    assert d["roofline"]["avg_launch_ms"] > 0 and d["cpu_baseline"] is None
+
+
+def test_bench_two_ranks_mixed_circuit_80bit():
+    """The same with BASELINE configs[4]'s gate mix (half Gates::mux, half hom_xor) at SECURITY_80_BIT."""
+    d = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2048", "--no-cpu-baseline",
+                    "--gate", "mixed", "--params", "SECURITY_80_BIT"], {"BENCH_SHARE_GPU": "1", "MASTER_PORT": "29549"})
+    assert d["n_gpus"] == 2 and d["decrypt_ok"] is True and "SECURITY_80_BIT" in d["metric"]
+
+
+def test_bench_pool_two_members_pinned_and_pageable():
+    """`bench.py --pool-devices 0,0`: ONE process, the multi-device handle a Rust caller binds (tfhe_hip_pool_*), two
+    member contexts on this GPU, host buffers -- pinned (zero-copy) and pageable (each member stages its shard
+    through its own pinned arena)."""
+    for extra in (["--pinned"], []):
+        d = _run_bench(["--pool-devices", "0,0", "--steps", "1", "--warmup", "1", "--batch", "2048"] + extra, {})
+        assert d["devices"] == [0, 0] and d["decrypt_ok"] is True and d["batch_total"] == 4096
+        assert d["host_memory"].startswith("pinned" if extra else "pageable")
