@@ -366,6 +366,9 @@ const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *pool);
 /* [lo, hi) of shard `shard` of `nshards` over `count` items: contiguous, sizes differ by at most one, earlier
  * shards take the remainder (the split every pool batch call uses). */
 void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_t *hi);
+/* Members a batch of `count` is actually spread over (= the nshards of its split): min(size, ceil(count / 256)),
+ * at least 1 -- one device runs up to 256 ciphertexts in the time of one, so small batches are not cut thinner. */
+int tfhe_hip_pool_members_for(const tfhe_hip_pool *pool, size_t count);
 
 /* Cloud key for every member: same arguments and meaning as the tfhe_hip_*_cloud_key calls above. */
 int tfhe_hip_pool_load_cloud_key(tfhe_hip_pool *pool, const double *bsk, const uint32_t *ksk, uint32_t decomp_offset,

@@ -67,6 +67,9 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 #ifndef TFHE_PREFETCH_B
 #define TFHE_PREFETCH_B 4
 #endif
+#ifndef TFHE_L1_PA  // cap on TFHE_PREFETCH_A at L == 1 (a whole a-half in flight spilled there in round 2)
+#define TFHE_L1_PA 6
+#endif
 // 1 = the inverse-pass-3 twiddles (20 VGPRs) are re-read from the cache-resident table before the inverse
 // transforms of each CMUX step instead of living in registers across the forward phase (measured: 432 vs 469 ms
 // on the round-2 kernel before the workgroup change, profiles/exp/logs/r2a_ab_fft_v2_and_ablations.log)
@@ -135,7 +138,7 @@ __device__ __forceinline__ void external_product_row(int r, int shift, const uin
   const uint32_t row_off = bsk_i_off + (uint32_t)r * (2u * kN2 * 16u);
   f64x2 va[8], vb[8];
   // with a single digit row per half the schedule gets tighter: a whole a-half in flight spills there
-  constexpr int PA = (L == 1 && TFHE_PREFETCH_A > 6) ? 6 : TFHE_PREFETCH_A;
+  constexpr int PA = (L == 1 && TFHE_PREFETCH_A > TFHE_L1_PA) ? TFHE_L1_PA : TFHE_PREFETCH_A;
   constexpr int PB = TFHE_PREFETCH_B;
 #pragma unroll
   for (int s = 0; s < PA; ++s) va[s] = ldkey(bsk_rsrc, lane_off, row_off + (uint32_t)s * 1024u);
@@ -219,14 +222,16 @@ __device__ constexpr uint32_t kGateCb[11] = {0xFFFFFFFFu, 1u, 1u, 2u, 0xFFFFFFFE
 __device__ constexpr uint32_t kGateCc[11] = {0x20000000u, 0x20000000u, 0xE0000000u, 0x40000000u, 0xC0000000u, 0xE0000000u,
                                              0xE0000000u, 0xE0000000u, 0x20000000u, 0x20000000u, 0u};
 
-// LDS per workgroup: FFT tile | accumulator (a then b, natural order) | T2 table | rotation amounts
+// LDS per workgroup: per wave { FFT tile | accumulator (a then b, natural order) | rotation amounts }, then ONE
+// pass-2 twiddle table for the whole workgroup (every wave stores the same 64 entries).  Two workgroups share a
+// CU's 160 KiB up to n = 1183, i.e. for every parameter set (n <= 1160).
 constexpr int kAccBytes = 2 * kN * 4;
 constexpr int kBrWaves = TFHE_WG_WAVES;  // waves (= ciphertexts) per workgroup of k_blind_rotate
 __host__ __device__ __forceinline__ size_t blind_rotate_wave_lds_bytes(int n) {
-  return ((size_t)kTileBytes + kAccBytes + kT2Bytes + (size_t)n * 2 + 15) & ~(size_t)15;
+  return ((size_t)kTileBytes + kAccBytes + (size_t)n * 2 + 15) & ~(size_t)15;
 }
 __host__ __device__ __forceinline__ size_t blind_rotate_lds_bytes(int n) {
-  return kBrWaves * blind_rotate_wave_lds_bytes(n);
+  return kBrWaves * blind_rotate_wave_lds_bytes(n) + kT2Bytes;
 }
 constexpr int kStageLdsBytes = kTileBytes + kT2Bytes;  // stage kernels: tile | T2 table
 
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
   unsigned char *smem = smem_wg + (size_t)wave * blind_rotate_wave_lds_bytes(n);
   double2 *tile = reinterpret_cast<double2 *>(smem);
   uint32_t *acc = reinterpret_cast<uint32_t *>(smem + kTileBytes);
-  double2 *t2tab = reinterpret_cast<double2 *>(smem + kTileBytes + kAccBytes);
-  uint16_t *s_abar = reinterpret_cast<uint16_t *>(smem + kTileBytes + kAccBytes + kT2Bytes);
+  uint16_t *s_abar = reinterpret_cast<uint16_t *>(smem + kTileBytes + kAccBytes);
+  double2 *t2tab = reinterpret_cast<double2 *>(smem_wg + (size_t)kBrWaves * blind_rotate_wave_lds_bytes(n));
   // a partly filled last workgroup: the spare waves redo the last ciphertext (they take part in the
   // barriers) and store nothing
   size_t ct = (size_t)blockIdx.x * kBrWaves + wave;

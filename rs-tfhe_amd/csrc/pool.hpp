@@ -163,6 +163,8 @@ tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
 
 const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
 
+int tfhe_hip_pool_members_for(const tfhe_hip_pool *p, size_t count) { return p ? pool_world_for(p, count) : 0; }
+
 void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_t *hi) {
   size_t a = 0, b = 0;
   if (nshards > 0 && shard >= 0 && shard < nshards) pool_shard(count, shard, nshards, a, b);

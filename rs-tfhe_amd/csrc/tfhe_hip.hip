@@ -217,6 +217,15 @@ br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
   }
 }
 
+br_kernel_t br_wide_kernel(const tfhe_hip_ctx *ctx) {
+  const bool f = ctx->fast_round;
+  switch (ctx->P.l) {
+    case 1: return f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>;
+    case 2: return f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>;
+    default: return f ? k_blind_rotate_wide<3, true> : k_blind_rotate_wide<3, false>;
+  }
+}
+
 typedef void (*ep_kernel_t)(const uint32_t *, const int32_t *, const double2 *, uint32_t, const double2 *, int,
                             uint32_t, uint32_t *);
 ep_kernel_t ep_kernel(const tfhe_hip_ctx *ctx) {
@@ -263,16 +272,8 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
   // small batches: one workgroup of 2l waves per ciphertext (latency kernel)
   if (ctx->br_wide && count <= ctx->wide_max) {
-    typedef void (*wide_kernel_t)(BlindRotateArgs);
-    wide_kernel_t kern;
-    const bool f = ctx->fast_round;
-    switch (ctx->P.l) {
-      case 1: kern = f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>; break;
-      case 2: kern = f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>; break;
-      default: kern = f ? k_blind_rotate_wide<3, true> : k_blind_rotate_wide<3, false>; break;
-    }
+    br_kernel_t kern = br_wide_kernel(ctx);
     const size_t wlds = blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
-    HIPCHK(ctx, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds));
     CHK(record_begin(ctx, s, ctx->ev_br));
     hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(128 * ctx->P.l), wlds, s, A);
     HIPCHK(ctx, hipGetLastError());
@@ -296,8 +297,6 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * kBrWaves;
   }
   if (chunk == 0 || chunk > count) chunk = count;
-  if (lds > 64 * 1024)
-    HIPCHK(ctx, hipFuncSetAttribute((const void *)br_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (size_t done = 0; done < count; done += chunk) {
     const size_t m = (count - done < chunk) ? count - done : chunk;
     BlindRotateArgs S = A;
@@ -589,7 +588,7 @@ int to_host(tfhe_hip_ctx *ctx, void *dst, const DevBuf &b, size_t bytes) {
 // those PCIe transactions spread over the whole launch instead of three staging copies around it.
 // Returns the device view of `p`, or nullptr when `p` is ordinary pageable memory.
 template <class T>
-T *pinned_view(T *p) {
+T *pinned_view(T *p, size_t bytes) {
   if (!p) return nullptr;
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, (const void *)p) != hipSuccess) {
@@ -597,6 +596,26 @@ T *pinned_view(T *p) {
     return nullptr;
   }
   if (at.type != hipMemoryTypeHost) return nullptr;
+  // the LAST byte must belong to the same pinned allocation / registration as the first: a range registered
+  // shorter than the operand (or an interior pointer near the end of one) would fault in the kernel, where the
+  // staged path works -- so such operands are staged
+  if (bytes > 1) {
+    hipPointerAttribute_t last;
+    const void *q = (const void *)((const unsigned char *)p + bytes - 1);
+    if (hipPointerGetAttributes(&last, q) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    if (last.type != hipMemoryTypeHost) return nullptr;
+    void *b0 = nullptr, *b1 = nullptr;
+    size_t s0 = 0, s1 = 0;
+    if (hipMemGetAddressRange((hipDeviceptr_t *)&b0, &s0, (hipDeviceptr_t)p) == hipSuccess &&
+        hipMemGetAddressRange((hipDeviceptr_t *)&b1, &s1, (hipDeviceptr_t)q) == hipSuccess) {
+      if (b0 != b1) return nullptr;
+    } else {
+      (void)hipGetLastError();  // registered (not allocated) memory may have no address range: both ends are host-pinned
+    }
+  }
   void *d = nullptr;
   if (hipHostGetDevicePointer(&d, (void *)p, 0) != hipSuccess) {
     (void)hipGetLastError();
@@ -674,6 +693,14 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
+  // dynamic LDS above the 64 KiB default, declared once per context for the kernels of this parameter set
+  {
+    const size_t lds = blind_rotate_lds_bytes(p->n), wlds = blind_rotate_wide_lds_bytes(p->n, p->l);
+    if ((e = hipFuncSetAttribute((const void *)br_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+      return bail("hipFuncSetAttribute(k_blind_rotate)", e);
+    if ((e = hipFuncSetAttribute((const void *)br_wide_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)) != hipSuccess)
+      return bail("hipFuncSetAttribute(k_blind_rotate_wide)", e);
+  }
   std::vector<double2> tw;
   make_twiddles(tw);
   if ((e = hipMalloc((void **)&ctx->d_tw, tw.size() * sizeof(double2))) != hipSuccess)
@@ -829,6 +856,18 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   if (!ctx->K->d_ksk)
     HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
   if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
+  // The secret keys, the spectrum of the ring key and the generator key do not outlive the call on the device,
+  // whichever way it ends: the guard zeroes the four staging buffers and drains the stream on every exit path
+  // (an early return would otherwise leave them in buffers that later batches reuse as plain staging space, and
+  // could return while an asynchronous copy still reads this frame).
+  struct Wipe {
+    tfhe_hip_ctx *c;
+    ~Wipe() {
+      for (DevBuf *b : {&c->h_a, &c->h_b, &c->h_c, &c->h_idx})
+        if (b->p) (void)hipMemsetAsync(b->p, 0, b->cap < 65536 ? b->cap : 65536, c->stream);
+      (void)hipStreamSynchronize(c->stream);
+    }
+  } wipe{ctx};
   CHK(to_dev(ctx, ctx->h_a, key_lv0, (size_t)P.n * 4));
   CHK(to_dev(ctx, ctx->h_b, key_lv1, (size_t)kN * 4));
   CHK(ensure(ctx, ctx->h_c, (size_t)kN2 * sizeof(double2)));
@@ -838,7 +877,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   HIPCHK(ctx, hipGetLastError());
   // the generator key travels in a device buffer (not in kernel-argument memory) and is wiped with the other secrets
   CHK(ensure(ctx, ctx->h_idx, sizeof(ChaChaKey)));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->h_idx.p, &rk, sizeof(ChaChaKey), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpy(ctx->h_idx.p, &rk, sizeof(ChaChaKey), hipMemcpyHostToDevice));  // synchronous: rk is the caller's stack
   const ChaChaKey *d_rk = (const ChaChaKey *)ctx->h_idx.p;
   const dim3 bgrid((unsigned)(P.n * 2 * P.l));
   switch (P.l) {
@@ -856,12 +895,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   std::vector<uint32_t> tv(2 * kN, 0u);
   for (int i = 0; i < kN; ++i) tv[kN + i] = 0x20000000u;  // f64_to_torus(0.125)
   HIPCHK(ctx, hipMemcpyAsync(ctx->K->d_testvec, tv.data(), 2 * kN * 4, hipMemcpyHostToDevice, ctx->stream));
-  // the secret keys and the spectrum of the ring key do not outlive the call on the device
-  HIPCHK(ctx, hipMemsetAsync(ctx->h_a.p, 0, (size_t)P.n * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->h_b.p, 0, (size_t)kN * 4, ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->h_c.p, 0, (size_t)kN2 * sizeof(double2), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->h_idx.p, 0, sizeof(ChaChaKey), ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // (the local test vector above is read by an asynchronous copy)
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = off;
   ctx->K->key_loaded = true;
@@ -1083,8 +1117,8 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
   if (!a || !out || (gp.cb && !b)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   {  // all operands pinned: no staging (see pinned_view)
-    const uint32_t *da = pinned_view(a), *db = gp.cb ? pinned_view(b) : nullptr;
-    uint32_t *dout = pinned_view(out);
+    const uint32_t *da = pinned_view(a, bytes), *db = gp.cb ? pinned_view(b, bytes) : nullptr;
+    uint32_t *dout = pinned_view(out, bytes);
     if (da && dout && (!gp.cb || db)) {
       CHK(gate_dev(ctx, gate, da, db, dout, count, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1110,8 +1144,8 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   CHK(to_dev(ctx, ctx->h_idx, gates, count));  // one byte per ciphertext: always staged
   {
-    const uint32_t *da = pinned_view(a), *db = pinned_view(b);
-    uint32_t *dout = pinned_view(out);
+    const uint32_t *da = pinned_view(a, bytes), *db = pinned_view(b, bytes);
+    uint32_t *dout = pinned_view(out, bytes);
     if (da && db && dout) {
       CHK(gates_mixed_dev(ctx, (const uint8_t *)ctx->h_idx.p, da, db, dout, count, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1155,15 +1189,15 @@ int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   const uint32_t *d_tv = nullptr;
   if (testvec) {
-    d_tv = pinned_view(testvec);
+    d_tv = pinned_view(testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4);
     if (!d_tv) {
       CHK(to_dev(ctx, ctx->h_tv, testvec, (per_ct ? count : 1) * (size_t)2 * kN * 4));
       d_tv = (const uint32_t *)ctx->h_tv.p;
     }
   }
   {
-    const uint32_t *din = pinned_view(in);
-    uint32_t *dout = pinned_view(out);
+    const uint32_t *din = pinned_view(in, bytes);
+    uint32_t *dout = pinned_view(out, bytes);
     if (din && dout) {
       CHK(bootstrap_dev(ctx, din, d_tv, per_ct, keyswitch, dout, count, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1245,8 +1279,8 @@ int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const ui
   if (!a || !b || !c || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
   const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
   {
-    const uint32_t *da = pinned_view(a), *db = pinned_view(b), *dc = pinned_view(c);
-    uint32_t *dout = pinned_view(out);
+    const uint32_t *da = pinned_view(a, bytes), *db = pinned_view(b, bytes), *dc = pinned_view(c, bytes);
+    uint32_t *dout = pinned_view(out, bytes);
     if (da && db && dc && dout) {
       CHK(mux_dev(ctx, naive, da, db, dc, dout, count, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

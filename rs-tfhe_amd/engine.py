@@ -564,9 +564,15 @@ class Pool:
             msg = self._lib.tfhe_hip_pool_last_error(self._h)
             raise _capi.TfheHipError(rc, msg.decode() if msg else "")
 
+    def members_for(self, count: int) -> int:
+        """Members a batch of `count` is spread over (`tfhe_hip_pool_members_for`): small batches use fewer."""
+        return int(self._lib.tfhe_hip_pool_members_for(self._h, count))
+
     def shard(self, count: int, member: int) -> tuple:
+        """[lo, hi) of the batch that `member` runs -- over the members the call actually uses (members_for),
+        so (0, 0) for a member a small batch leaves idle."""
         lo, hi = C.c_size_t(0), C.c_size_t(0)
-        self._lib.tfhe_hip_pool_shard(count, member, len(self), C.byref(lo), C.byref(hi))
+        self._lib.tfhe_hip_pool_shard(count, member, self.members_for(count), C.byref(lo), C.byref(hi))
         return int(lo.value), int(hi.value)
 
     # -- cloud key ------------------------------------------------------------

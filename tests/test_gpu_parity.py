@@ -1036,7 +1036,8 @@ def test_pool_two_contexts_bit_exact_and_order_preserving(O, eng128, keys128):
     pk = _cloud_key(ck)
     P = pk.params
     pool = R.Pool(P, [0, 0])
-    assert len(pool) == 2 and pool.shard(5, 0) == (0, 3) and pool.shard(5, 1) == (3, 5)
+    assert len(pool) == 2 and pool.members_for(5) == 1 and pool.shard(5, 0) == (0, 5) and pool.shard(5, 1) == (0, 0)
+    assert pool.members_for(600) == 2 and pool.shard(601, 0) == (0, 301) and pool.shard(601, 1) == (301, 601)
     pool.load_cloud_key(pk)
     k0, k1 = pool.export_cloud_key(0), pool.export_cloud_key(1)
     assert np.array_equal(k1.bootstrapping_key, k0.bootstrapping_key) and np.array_equal(k1.key_switching_key, k0.key_switching_key)
