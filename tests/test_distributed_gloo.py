@@ -62,6 +62,10 @@ def _worker(rank, world, port, q):
                              else torch.zeros(n, dtype=torch.uint8) for n in (4096, 1024, 64)]
                 self.off = 0x82080000 if fill else 0
                 self.adopted = None
+                self.synced = 0
+
+            def synchronize(self):  # receivers drain their engine before their key buffers are overwritten
+                self.synced += 1
 
             def cloud_key_device_tensors(self):
                 return self.bufs[0], self.bufs[1], self.bufs[2], self.off
@@ -74,6 +78,7 @@ def _worker(rank, world, port, q):
         want = FakeEngine(True)
         ok = ok and all(torch.equal(a, b) for a, b in zip(fe.bufs, want.bufs))
         ok = ok and fe.adopted == (None if rank == 0 else 0x82080000)
+        ok = ok and fe.synced == (0 if rank == 0 else 1)
         # barrier + max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
