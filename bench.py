@@ -99,6 +99,33 @@ def pool_mode(args):
         "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
 
 
+def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch):
+    """Roofline of the second kernel.  Base-4 sets at batch sizes the matrix-core kernel takes: int8 MFMA ops of the
+    one-hot contraction (2 x ciphertexts x 4*N*t rows x padded output columns x 4 byte planes) against the guide's
+    measured i8 ceiling (3,944 TOPS, v_mfma_i32_16x16x64_i8; 32x32x32: 4,404), with the clock the kernel sustained
+    (the matrix pipes are current-limited: 1.6-2.4 GHz depending on operand toggling,
+    profiles/exp/logs/r3d_ubench_mfma.log).  Other sets: the LDS-ring kernels, instruction-issue bound."""
+    mfma = P.basebit == 2 and batch >= 1024 and os.environ.get("TFHE_HIP_KS_MFMA", "1") != "0"
+    out = {"avg_launch_ms": round(ks_ms, 3)}
+    if mfma and ks_ms > 0:
+        cols = -(-(P.n + 1) // 32) * 32
+        ops = 2.0 * per_launch * (4 * 1024 * P.iks_t) * cols * 4
+        tops = ops / (ks_ms * 1e-3) / 1e12
+        mhz = ks_clk.get("shader_mhz") or None
+        out.update({
+            "kernel": "k_key_switch_mfma", "bound": "mfma_i8", "achieved": round(tops, 1), "peak": 3944.0, "unit": "TOP/s",
+            "frac": round(tops / 3944.0, 4), "int8_ops_per_launch": ops, "shader_mhz": round(mhz, 1) if mhz else None,
+            # the same ops against what the pipes deliver at the clock they were allowed: 1,024 SIMDs x 2,048 ops/clk
+            "frac_at_sustained_clock": round(tops * 1e12 / (1024 * 2048 * mhz * 1e6), 4) if mhz else None,
+        })
+    else:
+        out.update({"bound": "valu+salu issue", "issue_frac": pm.get("key_switch", {}).get("issue_frac")})
+    out["algorithmic_hbm_GBps"] = round(P.ksk_touched_bytes * per_launch / (ks_ms * 1e-3) / 1e9, 1) if ks_ms > 0 else None
+    out["physical_hbm_frac"] = (round(pm["key_switch"]["hbm_bytes_per_launch"] / (ks_ms * 1e-3) / 8e12, 4)
+                                if pm.get("key_switch", {}).get("hbm_bytes_per_launch") and ks_ms > 0 else None)
+    return out
+
+
 def main():
     args = parse()
     if args.pool_devices:
@@ -235,6 +262,7 @@ def main():
     eng.set_profiling(False)
     kt = eng.kernel_times()
     clk = eng.clock_sample()
+    ks_clk = eng.key_switch_clock_sample()
     watts = sorted(watts[len(watts) // 4:])  # drop the ramp
     power_w = round(watts[len(watts) // 2]) if watts and watts[-1] > 0 else None
     power_cap_w = None
@@ -282,11 +310,26 @@ def main():
     achieved = (br_bytes_per_ct * per_launch) / (br_ms * 1e-3) / 1e9 if br_ms > 0 else 0.0
     # PMC counters cannot be read live: per-launch figures for this exact workload from the committed profile
     # (profiles/pmc_roofline.json, written by profiles/collect.sh from separate --pmc passes)
-    pm = {}
+    # An entry is quoted only if it was measured on THIS tree: its stamp (digest of rs-tfhe_amd/csrc/*) must equal
+    # the digest of the sources being timed; otherwise `traffic` is null and traffic_source says why.
+    import glob
+    import hashlib
+
+    hsrc = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "rs-tfhe_amd", "csrc", "*.h*"))):
+        hsrc.update(os.path.basename(f).encode())
+        hsrc.update(open(f, "rb").read())
+    csrc_sha = hsrc.hexdigest()[:16]
+    pm, traffic_source = {}, "none: no profiles/pmc_roofline.json entry for this workload"
     try:
         for entry in json.load(open(os.path.join(ROOT, "profiles", "pmc_roofline.json"))):
             if entry["config"] == {"params": args.params, "batch": B, "gate": args.gate}:
-                pm = entry
+                if entry.get("source", {}).get("csrc_sha256") == csrc_sha:
+                    pm = entry
+                    traffic_source = f"profiles/pmc_roofline.json entry '{entry['tag']}' (separate --pmc passes, same kernel sources {csrc_sha})"
+                elif not pm:
+                    traffic_source = (f"none: entry '{entry['tag']}' was measured on other kernel sources "
+                                      f"({entry.get('source', {}).get('csrc_sha256', 'unstamped')} != {csrc_sha}); re-run profiles/collect.sh")
     except Exception:
         pass
     traffic = pm.get("blind_rotate", {}).get("hbm_bytes_per_launch")
@@ -295,16 +338,20 @@ def main():
     try:
         isa = json.load(open(os.path.join(ROOT, "rs-tfhe_amd", "kernel_isa.json")))[f"l{P.l}"]
         isa_source = "rs-tfhe_amd/kernel_isa.json (this build)"
-    except (OSError, KeyError, ValueError):  # library built without the Makefile's ISA step: the round-2 counts
-        isa = {1: {"f64_flop_per_lane": 1946, "valu": 1335, "f64_fma": 876, "f64_add": 120, "f64_mul": 74, "f64_other": 32},
-               2: {"f64_flop_per_lane": 3066, "valu": 1962, "f64_fma": 1436, "f64_add": 120, "f64_mul": 74, "f64_other": 64},
-               3: {"f64_flop_per_lane": 4186, "valu": 2588, "f64_fma": 1996, "f64_add": 120, "f64_mul": 74, "f64_other": 96}}[P.l]
-        isa_source = "fallback table (round-2 build)"
+    except (OSError, KeyError, ValueError):
+        # library built without the Makefile's ISA step: the executed-flop roofline cannot be priced for THIS build.
+        # The ALGORITHMIC count of SURVEY 8(d) (258,048 flops per CMUX step at l = 3, scaled by the FFT count for
+        # other l) is used instead and the line says so; the ISA-derived issue fractions are null.
+        alg = ((2 * P.l + 2) * 26112 + 2 * P.l * 8192) // 64  # per lane: (2l+2) transforms + 2l x 2 x 512 complex MACs; 258,048 / 64 at l = 3
+        isa = {"f64_flop_per_lane": alg, "valu": None, "f64_fma": None, "f64_add": None, "f64_mul": None, "f64_other": None}
+        isa_source = "MISSING rs-tfhe_amd/kernel_isa.json: algorithmic flops only (run `make -C rs-tfhe_amd/csrc`)"
+        print("bench.py: " + isa_source, file=sys.stderr)
     wave_steps_per_s = P.n * per_launch / (br_ms * 1e-3) if br_ms > 0 else 0.0  # CMUX steps of one wave, whole chip
     tflops = wave_steps_per_s * 64 * isa["f64_flop_per_lane"] / 1e12
     shader_mhz = clk["shader_mhz"] or None
     # issue slots: 1,024 SIMDs, one FP64 wave-instruction per 4 cycles (16 lanes/clk), at the clock the kernel ran at
-    f64_instr = isa["f64_fma"] + isa["f64_add"] + isa["f64_mul"] + isa.get("f64_other", 0)
+    have_isa = isa["valu"] is not None
+    f64_instr = (isa["f64_fma"] + isa["f64_add"] + isa["f64_mul"] + isa.get("f64_other", 0)) if have_isa else None
     simd_cycles_per_s = 1024 * (shader_mhz or 2400.0) * 1e6
     roofline = {
         "kernel": f"k_blind_rotate<{P.l}>",
@@ -314,7 +361,11 @@ def main():
         "unit": "TFLOP/s",
         "frac": round(tflops / 78.6, 4),
         "traffic": traffic,
+        "traffic_source": traffic_source,
         "avg_launch_ms": round(br_ms, 3),
+        # under the board's power cap time tracks energy, not cycles: the quantity that moves
+        "joules_per_launch": round(power_w * br_ms * 1e-3, 1) if power_w else None,
+        "microjoules_per_bootstrap": round(power_w * br_ms * 1e-3 / per_launch * 1e6, 2) if power_w and per_launch else None,
         "f64_flop_per_lane_per_cmux_step": isa["f64_flop_per_lane"],
         "valu_instr_per_cmux_step": isa["valu"],
         "instruction_mix_source": isa_source,
@@ -326,8 +377,8 @@ def main():
         # what this board sustains on nothing but v_fma_f64 over random operands (profiles/exp/logs/r2u_ubench_random_operands.log):
         # the 1,400 W cap holds that stream at 2,027 MHz = 66.4 TFLOP/s
         "frac_of_power_capped_fma_peak": round(tflops / 66.4, 4),
-        "valu_issue_frac": round(wave_steps_per_s * isa["valu"] * 4 / simd_cycles_per_s, 4),
-        "f64_issue_frac": round(wave_steps_per_s * f64_instr * 4 / simd_cycles_per_s, 4),
+        "valu_issue_frac": round(wave_steps_per_s * isa["valu"] * 4 / simd_cycles_per_s, 4) if have_isa else None,
+        "f64_issue_frac": round(wave_steps_per_s * f64_instr * 4 / simd_cycles_per_s, 4) if have_isa else None,
         # every bootstrap "consumes" the whole key once.  The key is shared through L1/L2, so this
         # exceeds the HBM peak by construction and is NOT a roofline fraction; physical_hbm_frac is.
         "algorithmic_hbm": {
@@ -341,15 +392,7 @@ def main():
         "algorithmic_hbm_ratio_to_peak": round(achieved / 8000.0, 4),
         "whole_path_algorithmic_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
         "key_switch_avg_launch_ms": round(ks_ms, 3),
-        "key_switch_issue_frac": pm.get("key_switch", {}).get("issue_frac"),
-        "key_switch": {
-            "avg_launch_ms": round(ks_ms, 3),
-            "bound": "valu+salu issue",
-            "issue_frac": pm.get("key_switch", {}).get("issue_frac"),
-            "algorithmic_hbm_GBps": round(P.ksk_touched_bytes * per_launch / (ks_ms * 1e-3) / 1e9, 1) if ks_ms > 0 else None,
-            "physical_hbm_frac": (round(pm["key_switch"]["hbm_bytes_per_launch"] / (ks_ms * 1e-3) / 8e12, 4)
-                                  if pm.get("key_switch", {}).get("hbm_bytes_per_launch") and ks_ms > 0 else None),
-        },
+        "key_switch": key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, B),
     }
 
     cpu = None

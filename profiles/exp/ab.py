@@ -122,12 +122,14 @@ def main():
             d = json.loads(line[-1])
             res.setdefault(lib, []).append(d)
             print(f"round {r} {os.path.basename(lib):28s} br {d['br_ms']:8.2f} ms  ks {d['ks_ms']:6.2f} ms  "
-                  f"{d['mhz']:7.1f} MHz {d.get('watts', 0):5d} W  digest {d['digest']}  decrypt_ok {d['decrypt_ok']}", flush=True)
+                  f"{d['mhz']:7.1f} MHz {d.get('watts', 0):5d} W  {d['br_ms'] * d.get('watts', 0) * 1e-3:6.1f} J  "
+                  f"digest {d['digest']}  decrypt_ok {d['decrypt_ok']}", flush=True)
     print("\nsummary (min / median blind-rotate ms over rounds)")
     for lib, ds in res.items():
         v = sorted(d["br_ms"] for d in ds)
         print(f"  {os.path.basename(lib):28s} min {v[0]:8.2f}  med {v[len(v) // 2]:8.2f}  "
-              f"ks {min(d['ks_ms'] for d in ds):6.2f}  mhz {ds[-1]['mhz']}  W {ds[-1].get('watts')}  Mcyc {v[0] * ds[-1]['mhz'] / 1e3:7.1f}  "
+              f"ks {min(d['ks_ms'] for d in ds):6.2f}  mhz {ds[-1]['mhz']}  W {ds[-1].get('watts')}  "
+              f"J/launch {min(d['br_ms'] * d.get('watts', 0) * 1e-3 for d in ds):6.1f}  Mcyc {v[0] * ds[-1]['mhz'] / 1e3:7.1f}  "
               f"digest {ds[-1]['digest']}")
 
 

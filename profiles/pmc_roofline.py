@@ -68,8 +68,30 @@ def kernel_entry(sub):
     return e
 
 
+def source_stamp():
+    """What the counters were measured on: a digest of the kernel sources and the CMUX-loop instruction counts of the
+    build (bench.py refuses to quote an entry whose stamp differs from the tree it is timing)."""
+    import glob
+    import hashlib
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "rs-tfhe_amd", "csrc", "*.h*"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    stamp = {"csrc_sha256": h.hexdigest()[:16]}
+    try:
+        isa = json.load(open(os.path.join(root, "rs-tfhe_amd", "kernel_isa.json")))
+        stamp["valu_per_cmux_step"] = {k: v["valu"] for k, v in isa.items()}
+    except (OSError, ValueError, KeyError):
+        pass
+    return stamp
+
+
 entry = {
     "tag": args.tag,
+    "source": source_stamp(),
     "config": {"params": args.params, "batch": args.batch, "gate": args.gate},
     "blind_rotate": kernel_entry("k_blind_rotate<"),
     "key_switch": kernel_entry("k_key_switch"),

@@ -68,7 +68,7 @@ __device__ __forceinline__ f64x2 ldkey(__amdgpu_buffer_rsrc_t rsrc, uint32_t lan
 #define TFHE_PREFETCH_B 4
 #endif
 #ifndef TFHE_L1_PA  // cap on TFHE_PREFETCH_A at L == 1 (a whole a-half in flight spilled there in round 2)
-#define TFHE_L1_PA 6
+#define TFHE_L1_PA 7
 #endif
 // 1 = the inverse-pass-3 twiddles (20 VGPRs) are re-read from the cache-resident table before the inverse
 // transforms of each CMUX step instead of living in registers across the forward phase (measured: 432 vs 469 ms

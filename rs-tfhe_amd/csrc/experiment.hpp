@@ -1,13 +1,14 @@
 // experiment.hpp -- guard for the timing-only ablation switches used by profiles/exp/ (NOT product behaviour).
 //
-// TFHE_ABL_NOKEY / NOLDS / NOFFT / TPB_DPP remove or replace parts of the blind rotation so that the cost of what
+// TFHE_ABL_NOKEY / NOLDS / NOFFT / TPB_DPP / KM_NOBARRIER remove or replace parts of the kernels so that the cost of what
 // is left can be measured (profiles/exp/logs/r2h_ab_energy_decomposition.log); the results of such a build are
 // WRONG BY CONSTRUCTION.  They can only be switched on together with -DTFHE_EXPERIMENT (what
 // profiles/exp/build_variants.sh passes); such a library reports itself as "hip-gfx950-EXPERIMENT" through
 // tfhe_hip_name() and rs_tfhe_amd refuses to load it unless TFHE_HIP_ALLOW_EXPERIMENT=1 is set.
 #pragma once
 #if (defined(TFHE_ABL_NOKEY) && TFHE_ABL_NOKEY) || (defined(TFHE_ABL_NOLDS) && TFHE_ABL_NOLDS) || \
-    (defined(TFHE_ABL_NOFFT) && TFHE_ABL_NOFFT) || (defined(TFHE_ABL_TPB_DPP) && TFHE_ABL_TPB_DPP)
+    (defined(TFHE_ABL_NOFFT) && TFHE_ABL_NOFFT) || (defined(TFHE_ABL_TPB_DPP) && TFHE_ABL_TPB_DPP) || \
+    (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER)
 #ifndef TFHE_EXPERIMENT
 #error "TFHE_ABL_* are timing-only experiment switches (results wrong by construction): build with -DTFHE_EXPERIMENT (profiles/exp/build_variants.sh)"
 #endif
@@ -26,4 +27,7 @@
 #endif
 #ifndef TFHE_ABL_TPB_DPP
 #define TFHE_ABL_TPB_DPP 0
+#endif
+#ifndef TFHE_ABL_KM_NOBARRIER  // matrix-core key switch without its per-step barrier (races: wrong results)
+#define TFHE_ABL_KM_NOBARRIER 0
 #endif

@@ -32,18 +32,25 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
+#include "experiment.hpp"
+
 namespace tfhe {
 
 #ifndef TFHE_KM_FRAGS  // experiment knobs (profiles/exp/build_variants.sh); the defaults are the product
-#define TFHE_KM_FRAGS 2
+#define TFHE_KM_FRAGS 1
 #endif
 #ifndef TFHE_KM_COLBLOCKS
-#define TFHE_KM_COLBLOCKS 4
+#define TFHE_KM_COLBLOCKS 2
 #endif
 constexpr int kKmWaves = 4;              // waves per workgroup (two workgroups per CU: 2 waves per SIMD)
 constexpr int kKmFrags = TFHE_KM_FRAGS;  // 32-row A fragments per wave: a key tile read from LDS feeds this many matrix instructions
 constexpr int kKmRows = 32 * kKmFrags * kKmWaves;  // ciphertexts per workgroup; level-1 buffers are padded to a multiple
-constexpr int kKmSlots = 4;              // ring depth in K-steps
+#ifndef TFHE_KM_SLOTS
+#define TFHE_KM_SLOTS 4
+#endif
+constexpr int kKmSlots = TFHE_KM_SLOTS;  // ring depth in K-steps
 constexpr int kKmAhead = kKmSlots - 1;   // DMA lead in K-steps
 constexpr int kKmAbBytes = 32 * kKmFrags * 16 * 4;  // one wave's a_bar stage: its rows x 16 coefficients
 constexpr int kKmAbQ = kKmAbBytes / 256; // dword DMA instructions per stage (256 B each)
@@ -217,11 +224,15 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
 
   km_i32x16 acc[R][NT];
   const uint32_t a_lane = (uint32_t)((lane & 31) * 64 + (lane >> 5) * 16);  // this lane's 4 words in a stage row
-  // A fragment f of step (blk, u): digit position j = u >> 1 of coefficients 16 blk + 8 (u & 1) + 4 kb + (0..3)
-  auto make_a = [&](const KmPos &q, int f) -> km_i32x4 {
-    const uint32_t sh = (uint32_t)(27 - 2 * (q.u >> 1));  // ((a_bar >> (30 - 2j)) & 3) * 8
+  // A fragment f of step (blk, u): digit position j = u >> 1 of coefficients 16 blk + 8 (u & 1) + 4 kb + (0..3).
+  // Reading the four a_bar words and building the one-hot bytes are separate so that the LDS latency of the read
+  // can be covered by matrix instructions.
+  auto read_a = [&](const KmPos &q, int f) -> km_u32x4 {
     const unsigned char *abuf = km_smem + off_ab + (uint32_t)(q.blk & 1) * kKmAbBytes + a_lane + (uint32_t)(q.u & 1) * 32u;
-    const km_u32x4 w = *reinterpret_cast<const km_u32x4 *>(abuf + f * (32 * 64));
+    return *reinterpret_cast<const km_u32x4 *>(abuf + f * (32 * 64));
+  };
+  auto build_a = [&](const KmPos &q, km_u32x4 w) -> km_i32x4 {
+    const uint32_t sh = (uint32_t)(27 - 2 * (q.u >> 1));  // ((a_bar >> (30 - 2j)) & 3) * 8
     km_u32x4 a;
     a.x = 1u << (((w.x + prec) >> sh) & 0x18u);
     a.y = 1u << (((w.y + prec) >> sh) & 0x18u);
@@ -229,11 +240,15 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
     a.w = 1u << (((w.w + prec) >> sh) & 0x18u);
     return __builtin_bit_cast(km_i32x4, a);
   };
+  auto make_a = [&](const KmPos &q, int f) -> km_i32x4 { return build_a(q, read_a(q, f)); };
   KmPos cur{0, 0};
   km_i32x4 A[R];
 #pragma unroll
   for (int f = 0; f < R; ++f) A[f] = make_a(cur, f);
-  constexpr int PRE = NT < 3 ? NT : 3;  // key tiles of a step read before its first matrix instruction
+#ifndef TFHE_KM_PRE
+#define TFHE_KM_PRE 3
+#endif
+  constexpr int PRE = NT < TFHE_KM_PRE ? NT : TFHE_KM_PRE;  // key tiles in flight ahead of the matrix instruction that consumes them
   constexpr int H = NT / 2;             // tiles consumed before the mid-step barrier
   km_i32x4 Bpre[PRE];
 #pragma unroll
@@ -246,56 +261,88 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
   // step g+1 have landed (one younger DMA group may be in flight), after the barrier everybody's have, and everybody
   // is done with step g-1, whose slot the next DMA group refills.  So the first key tiles of step g+1 and its A
   // fragments are fetched under the second half of step g's matrix instructions and no wave starts a step waiting.
+  // The second half is interleaved BY HAND (sched_barrier): one matrix instruction, then one piece of the step's
+  // other work (a DMA with its scalar address arithmetic, the next A fragment, ...), so that the ~60 non-matrix
+  // instructions of a step issue inside the 32-cycle shadows of the matrix pipe instead of in one block between two
+  // matrix instructions (what the scheduler does with the asm statements on its own).
+  auto run = [&](auto full_c) {
+    constexpr bool FULL = decltype(full_c)::value;  // every tile of the block exists (else the last one is skipped)
 #pragma unroll 1
-  for (int g = 0; g < S; ++g) {
-    const unsigned char *slot = km_smem + (uint32_t)(g % kKmSlots) * SLOT + v16;
-    const unsigned char *slot_next = km_smem + (uint32_t)((g + 1) % kKmSlots) * SLOT + v16;
-    km_i32x4 B[NT];
+    for (int g = 0; g < S; ++g) {
+      const unsigned char *slot = km_smem + (uint32_t)(g % kKmSlots) * SLOT + v16;
+      const unsigned char *slot_next = km_smem + (uint32_t)((g + 1) % kKmSlots) * SLOT + v16;
+      km_i32x4 B[NT];
 #pragma unroll
-    for (int c = 0; c < PRE; ++c) B[c] = Bpre[c];
+      for (int c = 0; c < PRE; ++c) B[c] = Bpre[c];
 #pragma unroll
-    for (int c = 0; c < H; ++c) {
-      if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
-#pragma unroll
-      for (int f = 0; f < R; ++f) acc[f][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[f], B[c], acc[f][c], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * OPS) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    {
-      dma_key(lds_base + (uint32_t)((g + D) % kKmSlots) * SLOT);
-      // a_bar words of the NEXT block into the other stage buffer: pieces R*u .. R*u + R-1 of the block (real while
-      // < kKmAbQ; the last real one is issued at step 7 of a block, >= D steps before the next block's first fragment)
-      const int nblk = (cur.blk + 1) & 63;
-      const uint32_t nbuf = lds_base + off_ab + (uint32_t)((cur.blk + 1) & 1) * kKmAbBytes;
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int q0 = R * cur.u + r;
-        const uint32_t *s0 = ab_row0 + (size_t)(4 * (q0 & (kKmAbQ - 1))) * (N + 1) + 16 * nblk;
-        const uint32_t d0 = q0 < kKmAbQ ? nbuf + (uint32_t)q0 * 256u : lds_base + off_dump;
-        km_dma4(v4, s0, d0);
-      }
-    }
-    if (++cur.u == spb) {
-      cur.u = 0;
-      cur.blk = (cur.blk + 1) & 63;
-    }
-    km_i32x4 A_next[R];
-#pragma unroll
-    for (int f = 0; f < R; ++f) A_next[f] = make_a(cur, f);
-#pragma unroll
-    for (int c = H; c < NT; ++c) {
-      if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
-      if (c < NT - 1 || full) {
+      for (int c = 0; c < H; ++c) {
+        if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
 #pragma unroll
         for (int f = 0; f < R; ++f) acc[f][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[f], B[c], acc[f][c], 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);  // the first half's matrix instructions stay ahead of the barrier
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * OPS) : "memory");
+      if (!TFHE_ABL_KM_NOBARRIER) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const uint32_t dslot = lds_base + (uint32_t)((g + D) % kKmSlots) * SLOT;
+      const int nblk = (cur.blk + 1) & 63;
+      const uint32_t nbuf = lds_base + off_ab + (uint32_t)((cur.blk + 1) & 1) * kKmAbBytes;
+      const int u_now = cur.u;
+      constexpr int PIECES = TPW + R + 2;
+      km_i32x4 A_next[R];
+      km_u32x4 Aw[R];
+      // piece `it` of the step's other work, one per matrix instruction of the second half.  First the LDS reads the
+      // NEXT step starts from (its a_bar words and first key tiles: valid after the barrier above) so that their
+      // latency lies under this step's remaining matrix instructions; then the TPW key DMAs and the R a_bar DMAs
+      // (pieces R*u .. R*u + R-1 of the next block, real while < kKmAbQ; the last real one is issued at step 7 of a
+      // block, >= D steps before that block's first fragment is built), with the one-hot bytes of the next A
+      // fragment as the second-to-last piece (so that only a short DMA trails the step's last matrix instruction).
+      auto piece = [&](int it) {
+        if (it == 0) {
+          if (++cur.u == spb) {
+            cur.u = 0;
+            cur.blk = (cur.blk + 1) & 63;
+          }
+#pragma unroll
+          for (int f = 0; f < R; ++f) Aw[f] = read_a(cur, f);
+#pragma unroll
+          for (int c = 0; c < PRE; ++c) Bpre[c] = *reinterpret_cast<const km_i32x4 *>(slot_next + c * 1024);
+        } else if (it == PIECES - 2) {  // second to last: the one-hot bytes, still inside a matrix shadow
+#pragma unroll
+          for (int f = 0; f < R; ++f) A_next[f] = build_a(cur, Aw[f]);
+        } else {  // the DMAs, in order: TPW key tiles, R a_bar pieces
+          const int d = it - 1 - (it > PIECES - 2 ? 1 : 0);
+          if (d < TPW) {
+            km_dma16(koff[d], kplane, dslot + (uint32_t)(wave + d * WAVES) * 1024u);
+            koff[d] += kstride;
+          } else {
+            const int q0 = R * u_now + (d - TPW);
+            const uint32_t *s0 = ab_row0 + (size_t)(4 * (q0 & (kKmAbQ - 1))) * (N + 1) + 16 * nblk;
+            km_dma4(v4, s0, q0 < kKmAbQ ? nbuf + (uint32_t)q0 * 256u : lds_base + off_dump);
+          }
+        }
+      };
+#pragma unroll
+      for (int c = H; c < NT; ++c) {
+        if (c + PRE < NT) B[c + PRE] = *reinterpret_cast<const km_i32x4 *>(slot + (c + PRE) * 1024);
+        if (c < NT - 1 || FULL) {
+#pragma unroll
+          for (int f = 0; f < R; ++f) acc[f][c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A[f], B[c], acc[f][c], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (c - H < PIECES) piece(c - H);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int it = NT - H; it < PIECES; ++it) piece(it);  // blocks with fewer tiles than pieces: the rest in a row
+#pragma unroll
+      for (int f = 0; f < R; ++f) A[f] = A_next[f];
     }
-#pragma unroll
-    for (int c = 0; c < PRE; ++c) Bpre[c] = *reinterpret_cast<const km_i32x4 *>(slot_next + c * 1024);
-#pragma unroll
-    for (int f = 0; f < R; ++f) A[f] = A_next[f];
-  }
+  };
+  if (full)
+    run(std::true_type{});
+  else
+    run(std::false_type{});
   // ---- merge this plane into the output ---------------------------------------------------------------
   // C tile element e of lane: row 32f + (e&3) + 8(e>>2) + 4(lane>>5), column 32c + (lane&31).  An address is one
   // per-lane offset + a wave-uniform one.
