@@ -107,6 +107,20 @@ __device__ __forceinline__ void wg_sync() {
   if (TFHE_WG_WAVES > 1 && TFHE_WG_SYNC >= LEVEL) __builtin_amdgcn_s_barrier();
 }
 
+// acc[j] += v in LDS.  1 (default): one ds_add_u32 without return -- the add happens in the LDS, nothing travels
+// to the registers and back (it was ds_read_b32 + v_add_u32 + ds_write_b32); a wave's LDS operations execute in
+// order, so the next step's reads see it.  0: the read-modify-write through registers.
+#ifndef TFHE_ACC_LDS_ADD
+#define TFHE_ACC_LDS_ADD 1
+#endif
+__device__ __forceinline__ void acc_add(uint32_t *p, uint32_t v) {
+#if TFHE_ACC_LDS_ADD
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+  *p += v;
+#endif
+}
+
 // f (+)= x * v, complex, as four fused multiply-adds (fma_in_fd_1024, trgsw.rs:118-142; the 0.5 of the
 // reference is in the key's 2^-10).  Written with explicit fma(): from `f += xr*v.x - xi*v.y` the
 // compiler makes mul + fma + add.
@@ -347,10 +361,10 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
       const int j = lane + 64 * m;
-      acc[j] += round_to_torus<FAST>(fa_re[m]);
-      acc[j + kN2] += round_to_torus<FAST>(fa_im[m]);
-      acc[kN + j] += round_to_torus<FAST>(fb_re[m]);
-      acc[kN + j + kN2] += round_to_torus<FAST>(fb_im[m]);
+      acc_add(&acc[j], round_to_torus<FAST>(fa_re[m]));
+      acc_add(&acc[j + kN2], round_to_torus<FAST>(fa_im[m]));
+      acc_add(&acc[kN + j], round_to_torus<FAST>(fb_re[m]));
+      acc_add(&acc[kN + j + kN2], round_to_torus<FAST>(fb_im[m]));
     }
 #else
     fft_inverse(fa_re, fa_im, tw, tile, lane);
@@ -550,8 +564,8 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
 #pragma unroll
       for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
         const int j = lane + 64 * m;
-        q[j] += round_to_torus<FAST>(f_re[m]);
-        q[j + kN2] += round_to_torus<FAST>(f_im[m]);
+        acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
+        acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
       }
     }
     LAT_STAMP(7);

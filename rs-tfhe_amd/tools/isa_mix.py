@@ -25,6 +25,8 @@ def klass(op):
         return "f64_other"  # conversions, rndne
     if op.startswith("v_"):
         return "valu_int"
+    if op.startswith("ds_add") or op.startswith("ds_sub"):
+        return "lds_atomic"
     if op.startswith("ds_"):
         wide = "b128" in op
         return ("lds_write" if "write" in op else "lds_read") + ("_b128" if wide else "_narrow")
