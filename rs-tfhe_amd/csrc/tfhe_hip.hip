@@ -76,7 +76,7 @@ struct tfhe_hip_ctx {
   bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
   int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
   int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
-  size_t ks_mfma_min = 1024;  // smallest batch the matrix-core kernel takes (below: split / LDS-ring kernels)
+  size_t ks_mfma_min = 512;  // smallest batch the matrix-core kernel takes (below: the split kernel)
   bool br_wide = true;      // small batches use the latency kernels
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
@@ -395,6 +395,14 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
   dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
   CHK(record_begin(ctx, s, ctx->ev_ks));
+  // base-4 sets from 512 ciphertexts up: the matrix-core kernel (0.55-0.75 ms for anything up to 8,192 ciphertexts --
+  // one round of workgroups -- against 0.55 ms at 512 and 3.7 ms at 4,096 for the split kernel,
+  // profiles/exp/logs/r3k_ks_crossover.log)
+  if (ks_mfma_wanted(ctx, count)) {
+    CHK(launch_key_switch_mfma(ctx, s, lv1, out, count));
+    CHK(record_end(ctx, s, ctx->ev_ks));
+    return TFHE_HIP_OK;
+  }
   if (ctx->br_wide && count <= ctx->ks_split_max) {
     // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
     const size_t kb = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
@@ -402,11 +410,6 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
     hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->K->d_ksk,
                        (uint32_t)kb, n, ctx->P.basebit, ctx->P.t, out);
     HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_ks));
-    return TFHE_HIP_OK;
-  }
-  if (ks_mfma_wanted(ctx, count)) {
-    CHK(launch_key_switch_mfma(ctx, s, lv1, out, count));
     CHK(record_end(ctx, s, ctx->ev_ks));
     return TFHE_HIP_OK;
   }
