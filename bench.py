@@ -312,13 +312,12 @@ def main():
     # (profiles/pmc_roofline.json, written by profiles/collect.sh from separate --pmc passes)
     # An entry is quoted only if it was measured on THIS tree: its stamp (digest of rs-tfhe_amd/csrc/*) must equal
     # the digest of the sources being timed; otherwise `traffic` is null and traffic_source says why.
-    import glob
     import hashlib
 
     hsrc = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "rs-tfhe_amd", "csrc", "*.h*"))):
-        hsrc.update(os.path.basename(f).encode())
-        hsrc.update(open(f, "rb").read())
+    for name in ("blind_rotate.hpp", "experiment.hpp", "fft512.hpp", "key_switch.hpp", "key_switch_mfma.hpp", "keygen.hpp"):
+        hsrc.update(name.encode())  # device code only (the same list as profiles/pmc_roofline.py)
+        hsrc.update(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", name), "rb").read())
     csrc_sha = hsrc.hexdigest()[:16]
     pm, traffic_source = {}, "none: no profiles/pmc_roofline.json entry for this workload"
     try:

@@ -356,6 +356,11 @@ typedef struct tfhe_hip_pool tfhe_hip_pool;
 int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int ndev, tfhe_hip_pool **out);
 void tfhe_hip_pool_destroy(tfhe_hip_pool *pool);
 int tfhe_hip_pool_size(const tfhe_hip_pool *pool);
+/* How the pool's last cloud key reached the members: "rccl" (one grouped ncclBroadcast per key buffer over xGMI,
+ * in place in the engine layouts; librccl is opened at run time; used when the pool's devices are distinct) or
+ * "peer-copy" (serial hipMemcpyPeer from member 0: the fallback, and what pools with a repeated device use).
+ * TFHE_HIP_POOL_RCCL=0 disables the RCCL path. */
+const char *tfhe_hip_pool_key_transport(const tfhe_hip_pool *pool);
 /* A key view of a pool: one tfhe_hip_key_create view per member (same devices, streams and scratch), accepted by
  * every tfhe_hip_pool_* entry point; tfhe_hip_pool_destroy(view) frees only its keys.  Destroy views first. */
 int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **key_view);

@@ -103,6 +103,7 @@ SIGNATURES = {
     "tfhe_hip_pool_destroy": (None, [_CTX]),
     "tfhe_hip_pool_size": (C.c_int, [_CTX]),
     "tfhe_hip_pool_members_for": (C.c_int, [_CTX, _SZ]),
+    "tfhe_hip_pool_key_transport": (C.c_char_p, [_CTX]),
     "tfhe_hip_pool_ctx": (_CTX, [_CTX, C.c_int]),
     "tfhe_hip_pool_last_error": (C.c_char_p, [_CTX]),
     "tfhe_hip_pool_shard": (None, [_SZ, C.c_int, C.c_int, C.POINTER(_SZ), C.POINTER(_SZ)]),

@@ -8,6 +8,9 @@
 // shard (each thread makes its shard's device current; the HIP current device is per thread), results
 // written in place into the caller's output slice.  No collective and no exchange on the data path.
 #pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is opened at run time (rccl_api)
+
 #include <system_error>
 #include <thread>
 
@@ -15,6 +18,7 @@ struct tfhe_hip_pool {
   std::vector<tfhe_hip_ctx *> ctxs;
   std::mutex mu;  // one batch at a time per pool (the contexts' host staging buffers are per context)
   std::string err = "";
+  bool replicated_by_rccl = false;  // how the last key reached the members (tfhe_hip_pool_key_transport)
 };
 
 namespace {
@@ -57,7 +61,125 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   return TFHE_HIP_OK;
 }
 
+// ---- key replication by RCCL broadcast (xGMI), when the pool's devices are distinct -------------------------
+// north_star: "RCCL over xGMI used only for the trivial scatter/gather": the one exchange this path has is the
+// replication of the cloud key (172 MB, once per key).  librccl is opened at run time (no link-time dependency: a
+// process that already carries torch's RCCL reuses it by SONAME); one communicator per pool, one grouped
+// ncclBroadcast per key buffer, in place in the engine layouts.  Anything that fails -- library absent, duplicate
+// devices (ncclCommInitAll refuses them), a transport error -- falls back to the serial hipMemcpyPeer path below.
+struct RcclApi {
+  void *lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  bool ok = false;
+};
+inline RcclApi &rccl_api() {
+  static RcclApi a = [] {
+    RcclApi r;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return r;
+    r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
+    r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
+    r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast;
+    return r;
+  }();
+  return a;
+}
+
+// member i >= 1: drained, its key buffers allocated, no valid key until finish_replica
+int prepare_replica(tfhe_hip_ctx *member) {
+  tfhe_hip_ctx *ctx = member;
+  ENTER(ctx);
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
+  const tfhe_hip_params &P = ctx->P;
+  ctx->K->key_loaded = false;
+  if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double)));
+  if (!ctx->K->d_ksk)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4 + 4096));
+  if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
+  return TFHE_HIP_OK;
+}
+int finish_replica(tfhe_hip_ctx *member, uint32_t offset) {
+  tfhe_hip_ctx *ctx = member;
+  ENTER(ctx);
+  HIPCHK(ctx, hipDeviceSynchronize());
+  CHK(build_ksk_planes(ctx));
+  ctx->K->offset = offset;
+  ctx->K->key_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+// true: every member holds member 0's key.  false: nothing usable happened (members >= 1 may hold garbage and are
+// marked unloaded): the caller takes the peer-copy path.
+bool replicate_key_rccl(tfhe_hip_pool *p) {
+  const int n = (int)p->ctxs.size();
+  const char *env = getenv("TFHE_HIP_POOL_RCCL");
+  const int mode = env ? atoi(env) : 1;  // 0 = never, 1 = pools of >= 2 members, 2 = also a pool of one (plumbing test)
+  if (mode == 0 || n < (mode >= 2 ? 1 : 2)) return false;
+  RcclApi &R = rccl_api();
+  if (!R.ok) return false;
+  std::vector<int> devs;
+  for (auto *c : p->ctxs) devs.push_back(c->device);
+  for (int i = 0; i < n; ++i)  // one rank per GPU: a pool that repeats a device takes the peer-copy path
+    for (int j = i + 1; j < n; ++j)
+      if (devs[(size_t)i] == devs[(size_t)j]) return false;
+  for (int i = 1; i < n; ++i)
+    if (prepare_replica(p->ctxs[(size_t)i]) != TFHE_HIP_OK) return false;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  if (R.CommInitAll(comms.data(), n, devs.data()) != ncclSuccess) {
+    (void)hipGetLastError();
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return false;
+  }
+  const tfhe_hip_params &P = p->ctxs[0]->P;
+  const size_t bytes[3] = {(size_t)P.n * 2 * P.l * 2 * kN * sizeof(double),
+                           (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4, (size_t)2 * kN * 4};
+  bool good = true;
+  for (int b = 0; b < 3 && good; ++b) {
+    good = R.GroupStart() == ncclSuccess;
+    for (int i = 0; i < n && good; ++i) {
+      tfhe_hip_ctx *c = p->ctxs[(size_t)i];
+      tfhe_hip_ctx *base = c->parent ? c->parent : c;
+      KeyState &k = c->own;
+      void *buf = b == 0 ? (void *)k.d_bsk : b == 1 ? (void *)k.d_ksk : (void *)k.d_testvec;
+      good = hipSetDevice(c->device) == hipSuccess &&
+             R.Broadcast(buf, buf, bytes[b], ncclUint8, 0, comms[(size_t)i], base->stream) == ncclSuccess;
+    }
+    good = (R.GroupEnd() == ncclSuccess) && good;
+  }
+  for (int i = 0; i < n; ++i) {
+    tfhe_hip_ctx *c = p->ctxs[(size_t)i];
+    tfhe_hip_ctx *base = c->parent ? c->parent : c;
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(base->stream) != hipSuccess) good = false;
+    (void)R.CommDestroy(comms[(size_t)i]);
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (!good) {
+    (void)hipGetLastError();
+    return false;
+  }
+  for (int i = 1; i < n; ++i)
+    if (finish_replica(p->ctxs[(size_t)i], p->ctxs[0]->own.offset) != TFHE_HIP_OK) return false;
+  p->replicated_by_rccl = true;
+  return true;
+}
+
 int replicate_key(tfhe_hip_pool *p) {
+  p->replicated_by_rccl = false;
+  if (replicate_key_rccl(p)) return TFHE_HIP_OK;
   for (size_t i = 1; i < p->ctxs.size(); ++i) {
     const int rc = clone_key(p->ctxs[i], p->ctxs[0]);
     if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(p->ctxs[i]->device) + ": " + tfhe_hip_last_error(p->ctxs[i]));
@@ -162,6 +284,10 @@ tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
 }
 
 const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+
+// "rccl" when the pool's last cloud key reached its members by ncclBroadcast, "peer-copy" when by hipMemcpyPeer
+// (or when there was nothing to replicate).
+const char *tfhe_hip_pool_key_transport(const tfhe_hip_pool *p) { return (p && p->replicated_by_rccl) ? "rccl" : "peer-copy"; }
 
 int tfhe_hip_pool_members_for(const tfhe_hip_pool *p, size_t count) { return p ? pool_world_for(p, count) : 0; }
 

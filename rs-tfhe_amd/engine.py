@@ -564,6 +564,11 @@ class Pool:
             msg = self._lib.tfhe_hip_pool_last_error(self._h)
             raise _capi.TfheHipError(rc, msg.decode() if msg else "")
 
+    @property
+    def key_transport(self) -> str:
+        """"rccl" / "peer-copy": how the last cloud key reached the members (`tfhe_hip_pool_key_transport`)."""
+        return self._lib.tfhe_hip_pool_key_transport(self._h).decode()
+
     def members_for(self, count: int) -> int:
         """Members a batch of `count` is spread over (`tfhe_hip_pool_members_for`): small batches use fewer."""
         return int(self._lib.tfhe_hip_pool_members_for(self._h, count))

@@ -750,6 +750,33 @@ def test_key_views_several_keys_on_one_context(O, eng128, keys128):
     pool.close()
 
 
+def test_pool_key_replication_transports(O, keys128, monkeypatch):
+    """The pool replicates its key by one grouped ncclBroadcast per key buffer when its devices are distinct (librccl
+    opened at run time) and by hipMemcpyPeer otherwise.  One GPU here: a pool of ONE member forced through the RCCL
+    path (TFHE_HIP_POOL_RCCL=2: communicator of one rank -- symbol loading, call sequence, stream handling) and a
+    pool that repeats the device (peer copies); both must evaluate under the right key afterwards."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    A = np.array([1, 0, 1, 1, 0], bool)
+    B = np.array([1, 1, 0, 1, 0], bool)
+    ca, cb = sk.encrypt_bool(A, 7301), sk.encrypt_bool(B, 7302)
+    want = O.batch_gate(ck, O.GATE_NAND, ca, cb)
+    monkeypatch.setenv("TFHE_HIP_POOL_RCCL", "2")
+    one = R.Pool(R.params.SECURITY_128_BIT, [0])
+    one.load_cloud_key(pk)
+    assert one.key_transport == "rccl"
+    assert np.array_equal(one.batch_gate(O.GATE_NAND, ca, cb), want)
+    one.close()
+    two = R.Pool(R.params.SECURITY_128_BIT, [0, 0])
+    two.load_cloud_key(pk)
+    assert two.key_transport == "peer-copy"
+    big = np.resize(np.arange(600) % 5, 600)
+    assert np.array_equal(two.batch_gate(O.GATE_NAND, ca[big], cb[big]), want[big])
+    two.close()
+
+
 def test_pinned_host_buffers_run_in_place(O, eng128, keys128):
     """tfhe_hip_host_alloc: when every ciphertext operand of a host-API call is pinned memory the kernels read and
     write it in place (no staging); results must be the same words as through pageable arrays, for every entry
