@@ -11,23 +11,27 @@
 // (v_mfma_i32_32x32x32_i8): |acc_p| <= N*t*128 < 2^21, no overflow, and the planes recombine as
 // sum_p acc_p << 8p with wrapping u32 arithmetic -- bit-exact, not approximately equal.
 //
-// Tiling: a workgroup of 4 waves owns 256 ciphertexts x one column block (half of the n+1 output words,
-// NT tiles of 32 columns); wave w owns rows 64w .. 64w+63 (two 32-row A fragments) of all NT tiles:
-// 2*NT accumulator tiles of 16 registers (352 at n = 700), one wave per SIMD.  One K-step is K = 32:
-// 8 digit groups (i, j) x 4 candidate rows k.
+// Tiling: a workgroup of kKmWaves = 4 waves owns 32 * kKmFrags * 4 ciphertexts x one column block (the
+// ceil((n+1)/32) output tiles are dealt to kKmColBlocks blocks as evenly as possible) x ONE byte plane; a wave owns
+// 32 * kKmFrags rows (kKmFrags A fragments) of all NT tiles of the block: kKmFrags * NT accumulator tiles of 16
+// registers.  Product defaults: one fragment, two column blocks (NT = 11 at n = 700: 176 accumulator registers,
+// two workgroups per CU, two waves per SIMD); two fragments x four blocks halves the LDS reads and the L2 -> LDS
+// traffic and measured 6 % slower (profiles/exp/logs/r3g_ab_ks_frags.log).  The four planes of an output word are
+// merged with integer atomics.  One K-step is K = 32: 8 digit groups (i, j) x 4 candidate rows k.
 //   * B (the key plane) is streamed global -> LDS by global_load_lds_dwordx4 into a 4-slot ring (one slot =
-//     NT KiB = one K-step for the whole workgroup), three steps ahead, handed over by a counted
-//     s_waitcnt vmcnt + one s_barrier per step; every wave reads all NT tiles of the slot (ds_read_b128,
-//     linear: conflict-free).  The key is laid out at load time in exactly this fragment order
-//     (k_ksk_planes), so a tile is one contiguous KiB.
+//     one K-step for the whole workgroup), three steps ahead, handed over by a counted s_waitcnt vmcnt + one
+//     s_barrier per step; every wave reads all tiles of the slot (ds_read_b128, linear: conflict-free).  The
+//     key is laid out at load time in exactly this fragment order (k_ksk_planes), so a tile is one contiguous KiB
+//     and a workgroup's whole walk one contiguous stream.
 //   * A (the one-hot) is never stored: a lane builds its 16 bytes of a fragment in registers from four
-//     a_bar words, dword c = 1 << 8*digit.  The a_bar words of the wave's 64 rows are staged 16
-//     coefficients at a time in a wave-private LDS buffer by dword DMAs issued one block ahead.
+//     a_bar words, dword c = 1 << 8*digit.  The a_bar words of the wave's rows are staged 16 coefficients at a
+//     time in a wave-private LDS buffer by dword DMAs issued one block ahead.
 //   * The order of the K axis is free (it is a sum); it is chosen so that a lane's four dwords of a step
 //     are the SAME digit position j of four consecutive coefficients: one ds_read_b128 and four
 //     (add, shift, and, shift) per fragment per step.
-// Bound: the matrix pipe.  65,536 x 704 x 32,768 x 4 planes x 2 = 1.21e16 int8 ops per launch at
-// SECURITY_128_BIT; the key planes cross L2 -> LDS once per workgroup (23.6 GB per launch).
+// Bound: the matrix pipes and the clock they are allowed (operand-toggling limited: profiles/exp/ubench_mfma.hip).
+// 65,536 x 704 x 36,864 x 4 planes x 2 = 1.36e16 int8 ops per launch at SECURITY_128_BIT (a quarter of them
+// against the zero k = 0 rows); the key planes cross L2 -> LDS once per workgroup (52 GB per launch).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
