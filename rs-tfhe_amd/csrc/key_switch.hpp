@@ -327,9 +327,10 @@ __global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__rest
 // ciphertexts per instruction (ds_read_b128 is serviced in 16-lane groups, so different rows per quarter
 // cost nothing); S accumulator sets per lane -> 4*S ciphertexts per wave, 16*S per workgroup of 4 waves.
 // The digit is per quarter, so the pick is two VALU instructions (v_bfe_u32, v_lshl_add_u32).
-constexpr int kKsSlSets = 32;      // S: accumulator sets per lane
+constexpr int kKsSlSets = 32;      // S: accumulator sets per lane (the default; the host picks S per launch, below)
 constexpr int kKsSlWaves = 4;
-constexpr int kKsSlCts = 4 * kKsSlSets * kKsSlWaves;  // ciphertexts per workgroup (512)
+__host__ __device__ constexpr int ks_sliced_cts(int sets) { return 4 * sets * kKsSlWaves; }  // ciphertexts per workgroup (512 at S = 32)
+constexpr int kKsSlCts = ks_sliced_cts(kKsSlSets);
 // coefficients whose a_bar words are staged in LDS at a time: 16, or 8 where the ring itself is large
 // (base 64: 3 x 16 KiB), so that two workgroups still share a CU's LDS
 __host__ __device__ __forceinline__ int ks_sliced_stage(int base) { return base >= 64 ? 8 : 16; }
@@ -338,16 +339,33 @@ constexpr int kKsSlSlots = 3;      // ring depth
 __host__ __device__ __forceinline__ uint32_t ks_sliced_slot_bytes(int base) {
   return (uint32_t)((base + 15) & ~15) * 256u;  // whole DMA instructions: 4 rows each, 4 waves
 }
-__host__ __device__ __forceinline__ size_t ks_sliced_lds_bytes(int base) {
-  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)kKsSlCts * ks_sliced_stage(base) * 4;
+__host__ __device__ __forceinline__ size_t ks_sliced_lds_bytes(int base, int sets = kKsSlSets) {
+  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)ks_sliced_cts(sets) * ks_sliced_stage(base) * 4;
+}
+// S is chosen per launch so that the grid fills whole rounds of the machine: a workgroup's time is proportional to
+// S, the grid is ceil(count / 16S) x slices workgroups, `slots` of them run at once, so the launch costs
+// ceil(grid / slots) x S.  At SECURITY_UINT4 (65,536 ciphertexts, 13 slices, 512 slots) S = 32 is 3.25 rounds = 4 x
+// 32; S = 36 is 2.9 rounds = 3 x 36: -16 %.
+__host__ inline int ks_sliced_pick_sets(size_t count, int slices, int slots) {
+  int best = kKsSlSets;
+  size_t best_cost = ~(size_t)0;
+  for (int sets : {24, 28, 32, 36, 40}) {
+    const size_t grid = ((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)) * (size_t)slices;
+    const size_t cost = ((grid + (size_t)slots - 1) / (size_t)slots) * (size_t)sets;
+    if (cost < best_cost || (cost == best_cost && sets == kKsSlSets)) {
+      best = sets;
+      best_cost = cost;
+    }
+  }
+  return best;
 }
 
-template <int IC>
+template <int IC, int S = kKsSlSets>
 __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__restrict__ lv1,  // [count][N+1]
                                                             const unsigned char *__restrict__ ksk,  // engine layout
                                                             int n, int basebit, int t,
                                                             uint32_t *__restrict__ out, size_t count) {
-  constexpr int N = 1024, S = kKsSlSets, NS = kKsSlSlots, D = NS - 1;
+  constexpr int N = 1024, NS = kKsSlSlots, D = NS - 1, CTS = ks_sliced_cts(S);
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
   const uint32_t base = 1u << basebit;
@@ -362,7 +380,7 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lane = (uint32_t)(tid & 63);
   const uint32_t sub = lane >> 4, c4 = lane & 15u;
-  const size_t ct0 = (size_t)blockIdx.x * kKsSlCts;
+  const size_t ct0 = (size_t)blockIdx.x * CTS;
   const uint32_t col0 = blockIdx.y * 64u;  // first column of this slice
   const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
   const uint32_t total = (uint32_t)N * (uint32_t)t;
@@ -394,7 +412,7 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
   for (int i0 = 0; i0 < N; i0 += IC) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int idx = tid; idx < kKsSlCts * IC; idx += 256) {
+    for (int idx = tid; idx < CTS * IC; idx += 256) {
       const int c = idx / IC, ii = idx % IC;
       const size_t ct = ct0 + c;
       s_ab[c][ii] = ct < count ? lv1[ct * (N + 1) + i0 + ii] + prec_offset : 0u;
@@ -420,7 +438,12 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
         dma_group(q + (uint32_t)D);
         const uint32_t sh = 32u - (uint32_t)(j + 1) * (uint32_t)basebit;
         const uint32_t lane_base = (q % NS) * slot_bytes + c4 * 16u;
-        constexpr int GB = 8;
+#ifndef TFHE_KS_SL_GB36
+#define TFHE_KS_SL_GB36 6
+#endif
+        // LDS reads in flight per lane before their subtractions; divides S (24 .. 40 in steps of 4)
+        constexpr int GB = S % 8 == 0 ? 8 : (S == 36 ? TFHE_KS_SL_GB36 : 4);
+        static_assert(S % GB == 0, "the read group must divide S");
 #pragma unroll
         for (int gb = 0; gb < S; gb += GB) {
           u32x4 v[GB];

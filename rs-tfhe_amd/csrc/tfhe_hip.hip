@@ -75,6 +75,7 @@ struct tfhe_hip_ctx {
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
   bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
   int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
+  int ks_sliced_sets = 0;  // 0: accumulator sets per lane picked per launch (ks_sliced_pick_sets); else forced (24..40)
   int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
   size_t ks_mfma_min = 512;  // smallest batch the matrix-core kernel takes (below: the split kernel)
   bool br_wide = true;      // small batches use the latency kernels
@@ -416,15 +417,27 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
   const size_t b4_lds = ks_b4_lds_bytes(bd >> 6, kKsG);
   const bool b4_fits = b4_lds <= 64 * 1024;
-  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);
+  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);  // at the default S; the launch re-derives it for the S it picks
   if ((ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024) {
-    dim3 sgrid((unsigned)((count + kKsSlCts - 1) / kKsSlCts), (unsigned)((n + 1 + 63) / 64));
-    if (ks_sliced_stage(1 << ctx->P.basebit) == 8)
-      hipLaunchKernelGGL(k_key_switch_sliced<8>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
-                         ctx->P.basebit, ctx->P.t, out, count);
-    else
-      hipLaunchKernelGGL(k_key_switch_sliced<16>, sgrid, dim3(256), sl_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
-                         ctx->P.basebit, ctx->P.t, out, count);
+    // accumulator sets per lane: whichever fills whole rounds of the machine (two workgroups per CU)
+    const int slices = (n + 1 + 63) / 64, base = 1 << ctx->P.basebit;
+    int sets = ks_sliced_pick_sets(count, slices, 2 * ctx->num_cus);
+    if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
+    if (ks_sliced_lds_bytes(base, sets) > 64 * 1024) sets = kKsSlSets;
+    const size_t lds = ks_sliced_lds_bytes(base, sets);
+    dim3 sgrid((unsigned)((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)), (unsigned)slices);
+    typedef void (*sl_kernel_t)(const uint32_t *, const unsigned char *, int, int, int, uint32_t *, size_t);
+    sl_kernel_t kern = nullptr;
+    const bool ic8 = ks_sliced_stage(base) == 8;
+    switch (sets) {
+      case 24: kern = ic8 ? k_key_switch_sliced<8, 24> : k_key_switch_sliced<16, 24>; break;
+      case 28: kern = ic8 ? k_key_switch_sliced<8, 28> : k_key_switch_sliced<16, 28>; break;
+      case 36: kern = ic8 ? k_key_switch_sliced<8, 36> : k_key_switch_sliced<16, 36>; break;
+      case 40: kern = ic8 ? k_key_switch_sliced<8, 40> : k_key_switch_sliced<16, 40>; break;
+      default: kern = ic8 ? k_key_switch_sliced<8, 32> : k_key_switch_sliced<16, 32>; break;
+    }
+    hipLaunchKernelGGL(kern, sgrid, dim3(256), lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n, ctx->P.basebit, ctx->P.t,
+                       out, count);
   } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
     hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
                        ctx->P.t, out, count);
@@ -687,6 +700,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_SLICED")) ctx->ks_sliced = atoi(env);
+  if (const char *env = getenv("TFHE_HIP_KS_SLICED_SETS")) {
+    const int v = atoi(env);
+    ctx->ks_sliced_sets = (v == 24 || v == 28 || v == 32 || v == 36 || v == 40) ? v : 0;
+  }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
   ctx->wide_max = 2 * (size_t)ctx->num_cus;      // measured crossover vs the batch kernel: ~640 ciphertexts

@@ -189,7 +189,10 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
     ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
     ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<6>, t = 8
-    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32)
+    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32), sets per lane picked per launch
+    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "36"}),   # ... forced to 36 sets (what a 65,536 batch picks) / 28 / 40
+    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "28"}),
+    ("SECURITY_UINT2", {"TFHE_HIP_KS_SLICED_SETS": "40"}),
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
     ("SECURITY_UINT2", {}),                                  # base 16
     ("SECURITY_UINT3", {}),                                  # k_key_switch_sliced, base 64, t = 2
@@ -210,7 +213,7 @@ def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, env):
     eng = R.Engine(pk.params, 0)
     eng.load_cloud_key(pk)
     rng = np.random.default_rng(27)
-    for count in (1, 33, 515) + ((1300,) if "TFHE_HIP_KS_MFMA" in env else ()):  # 256-row workgroups of the MFMA kernel
+    for count in (1, 33, 515) + ((1300,) if "TFHE_HIP_KS_MFMA" in env or "TFHE_HIP_KS_SLICED_SETS" in env else ()):  # several workgroups of rows
         lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
         lv1[0, :N] = 0
         lv1[-1, :N] = 0xFFFFFFFF
