@@ -515,6 +515,11 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // tmp = X^k*acc - acc (+ offset), digit d of it
       const int j = lane + 64 * m;
+      if (TFHE_ABL_LAT & 2) {  // timing-only: no rotated reads, no digit extraction
+        re[m] = (double)(k + m);
+        im[m] = (double)(lane - m);
+        continue;
+      }
       const uint32_t w_lo = (rot_read(p, j, k) - p[j] + offset) ^ signmask;
       const uint32_t w_hi = (rot_read(p, j + kN2, k) - p[j + kN2] + offset) ^ signmask;
       re[m] = (double)sbfe(w_lo, shift, bgbit);
@@ -524,10 +529,18 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
     fft_forward(re, im, tw, mytile, lane);
     wave_lds_sync();  // the transform's last tile reads are done: the tile becomes the fa-partial slot
     LAT_STAMP(2);
+    double2 keep_a[8], keep_b[8];  // (timing-only ablation bit 0: the products stay in registers, nothing is exchanged)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-      mytile[s * 64 + lane] = make_double2(re[s] * va[s].x - im[s] * va[s].y, re[s] * va[s].y + im[s] * va[s].x);
-      fb_mine[s * 64 + lane] = make_double2(re[s] * vb[s].x - im[s] * vb[s].y, re[s] * vb[s].y + im[s] * vb[s].x);
+      const double2 pa_ = make_double2(re[s] * va[s].x - im[s] * va[s].y, re[s] * va[s].y + im[s] * va[s].x);
+      const double2 pb_ = make_double2(re[s] * vb[s].x - im[s] * vb[s].y, re[s] * vb[s].y + im[s] * vb[s].x);
+      if (TFHE_ABL_LAT & 1) {
+        keep_a[s] = pa_;
+        keep_b[s] = pb_;
+      } else {
+        mytile[s * 64 + lane] = pa_;
+        fb_mine[s * 64 + lane] = pb_;
+      }
     }
     // next step's key row (clamped on the last step: a harmless re-read)
     const uint32_t nxt = (uint32_t)(i + 1 < n ? i + 1 : i) * per_i_bytes + my_row;
@@ -543,20 +556,28 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
       const double2 *src = wave == 0 ? tiles : fbpart;
       const size_t stride = wave == 0 ? (size_t)kTileCplx : (size_t)kN2;
       double f_re[8], f_im[8];
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        double2 v = src[s * 64 + lane];
-        f_re[s] = v.x;
-        f_im[s] = v.y;
-      }
-#pragma unroll
-      for (int w = 1; w < W; ++w)
+      if (TFHE_ABL_LAT & 1) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-          double2 v = src[(size_t)w * stride + s * 64 + lane];
-          f_re[s] += v.x;
-          f_im[s] += v.y;
+          f_re[s] = wave == 0 ? keep_a[s].x : keep_b[s].x;
+          f_im[s] = wave == 0 ? keep_a[s].y : keep_b[s].y;
         }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          double2 v = src[s * 64 + lane];
+          f_re[s] = v.x;
+          f_im[s] = v.y;
+        }
+#pragma unroll
+        for (int w = 1; w < W; ++w)
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            double2 v = src[(size_t)w * stride + s * 64 + lane];
+            f_re[s] += v.x;
+            f_im[s] += v.y;
+          }
+      }
       LAT_STAMP(5);
       fft_inverse(f_re, f_im, tw, tiles + (size_t)(W + wave) * kTileCplx, lane);
       LAT_STAMP(6);
@@ -564,6 +585,10 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
 #pragma unroll
       for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
         const int j = lane + 64 * m;
+        if (TFHE_ABL_LAT & 4) {  // timing-only: no rounding, no update (one store keeps the transform alive)
+          if (m == 0 && f_re[0] + f_im[7] == 1.2345) q[j] = 1u;
+          continue;
+        }
         acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
         acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
       }

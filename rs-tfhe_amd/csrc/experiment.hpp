@@ -8,7 +8,7 @@
 #pragma once
 #if (defined(TFHE_ABL_NOKEY) && TFHE_ABL_NOKEY) || (defined(TFHE_ABL_NOLDS) && TFHE_ABL_NOLDS) || \
     (defined(TFHE_ABL_NOFFT) && TFHE_ABL_NOFFT) || (defined(TFHE_ABL_TPB_DPP) && TFHE_ABL_TPB_DPP) || \
-    (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER)
+    (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER) || (defined(TFHE_ABL_LAT) && TFHE_ABL_LAT)
 #ifndef TFHE_EXPERIMENT
 #error "TFHE_ABL_* are timing-only experiment switches (results wrong by construction): build with -DTFHE_EXPERIMENT (profiles/exp/build_variants.sh)"
 #endif
@@ -27,6 +27,9 @@
 #endif
 #ifndef TFHE_ABL_TPB_DPP
 #define TFHE_ABL_TPB_DPP 0
+#endif
+#ifndef TFHE_ABL_LAT  // latency kernel: bit 0 no exchange of partial products, bit 1 no rotated reads / digits, bit 2 no update
+#define TFHE_ABL_LAT 0
 #endif
 #ifndef TFHE_ABL_KM_NOBARRIER  // matrix-core key switch without its per-step barrier (races: wrong results)
 #define TFHE_ABL_KM_NOBARRIER 0
