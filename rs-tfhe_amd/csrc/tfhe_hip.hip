@@ -21,6 +21,7 @@
 #include <sys/random.h>
 
 #include "blind_rotate.hpp"
+#include "blind_rotate_wide.hpp"
 #include "key_switch.hpp"
 #include "key_switch_mfma.hpp"
 #include "keygen.hpp"
@@ -79,6 +80,7 @@ struct tfhe_hip_ctx {
   int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
   size_t ks_mfma_min = 512;  // smallest batch the matrix-core kernel takes (below: the split kernel)
   bool br_wide = true;      // small batches use the latency kernels
+  bool br_wide2 = true;     // ... in their eight-wave form (blind_rotate_wide.hpp); false: one wave per row (round 1-2)
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
@@ -220,6 +222,11 @@ br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
 
 br_kernel_t br_wide_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
+  if (ctx->br_wide2) switch (ctx->P.l) {
+      case 1: return f ? k_blind_rotate_wide2<1, true> : k_blind_rotate_wide2<1, false>;
+      case 2: return f ? k_blind_rotate_wide2<2, true> : k_blind_rotate_wide2<2, false>;
+      default: return f ? k_blind_rotate_wide2<3, true> : k_blind_rotate_wide2<3, false>;
+    }
   switch (ctx->P.l) {
     case 1: return f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>;
     case 2: return f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>;
@@ -274,9 +281,10 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   // small batches: one workgroup of 2l waves per ciphertext (latency kernel)
   if (ctx->br_wide && count <= ctx->wide_max) {
     br_kernel_t kern = br_wide_kernel(ctx);
-    const size_t wlds = blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
+    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l) : blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
+    const unsigned wthreads = ctx->br_wide2 ? 64u * kWide2Waves : 128u * (unsigned)ctx->P.l;
     CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(128 * ctx->P.l), wlds, s, A);
+    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(wthreads), wlds, s, A);
     HIPCHK(ctx, hipGetLastError());
     CHK(record_end(ctx, s, ctx->ev_br));
     ctx->bootstraps += count;
@@ -710,12 +718,14 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
   ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_BR_WIDE2")) ctx->br_wide2 = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
   // dynamic LDS above the 64 KiB default, declared once per context for the kernels of this parameter set
   {
-    const size_t lds = blind_rotate_lds_bytes(p->n), wlds = blind_rotate_wide_lds_bytes(p->n, p->l);
+    const size_t lds = blind_rotate_lds_bytes(p->n);
+    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(p->n, p->l) : blind_rotate_wide_lds_bytes(p->n, p->l);
     if ((e = hipFuncSetAttribute((const void *)br_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate)", e);
     if ((e = hipFuncSetAttribute((const void *)br_wide_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)) != hipSuccess)
