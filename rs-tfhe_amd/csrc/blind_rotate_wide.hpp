@@ -30,6 +30,11 @@ __host__ __device__ __forceinline__ size_t blind_rotate_wide2_lds_bytes(int n, i
          ~(size_t)15;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
+// make every wave wait at each phase boundary for the key slots it has just prefetched for the NEXT step (measured:
+// 1,150 of 8,170 cycles per step, profiles/exp/logs/r3m_latency_wide2_phases.log).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int L, bool FAST>
 __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(BlindRotateArgs A) {
   constexpr int W = 2 * L;  // forward waves (one per decomposition row)
@@ -112,18 +117,33 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
 #pragma unroll 1
   for (int i = 0; i < n; ++i) {
     const int k = s_abar[i];
+    // Next step's key slots (clamped on the last step: a harmless re-read).  96 KiB per step go through the CU's one
+    // vector-memory path at 64 B per cycle = 1,536 cycles of it, and a wave is held at the instruction while the path's
+    // queue is full.  Issued by all eight waves before the barrier that ends P2, they delayed the inverse transforms by
+    // 900-1,150 cycles per step (measured, also with the loads hitting L1).  So the six waves that idle through P3
+    // issue theirs after that barrier, and waves 0 / 1 after their inverse transform, when the path is empty again.
+    auto load_next_keys = [&]() {
+      const uint32_t nxt = ((TFHE_ABL_LAT & 256) ? (uint32_t)(i & 1) : (uint32_t)(i + 1 < n ? i + 1 : i)) * per_i_bytes + my_slot;
+#pragma unroll
+      for (int r = 0; r < ((TFHE_ABL_LAT & 64) ? 0 : W); ++r) {
+        va[r] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)r * (2u * kN2 * 16u));
+        vb[r] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)r * (2u * kN2 * 16u) + (uint32_t)(kN2 * 16));
+      }
+    };
     double re[8], im[8];
     {
       // P0: my quarter of w = (X^k acc - acc + offset) ^ signmask for my half (trgsw.rs:183-186 + the digit offset)
       const uint32_t *p = acc + prep_half * kN;
       uint32_t *wb = wbuf + prep_half * kN;
+      if (!(TFHE_ABL_LAT & 128)) {
 #pragma unroll
-      for (int mm = 0; mm < 4; ++mm) {
-        const int j = lane + 64 * (4 * prep_idx + mm);
-        wb[j] = (rot_read(p, j, k) - p[j] + offset) ^ signmask;
+        for (int mm = 0; mm < 4; ++mm) {
+          const int j = lane + 64 * (4 * prep_idx + mm);
+          wb[j] = (rot_read(p, j, k) - p[j] + offset) ^ signmask;
+        }
       }
     }
-    __syncthreads();
+    lds_barrier();
     if (fwd) {
       const uint32_t *wb = wbuf + half_sel * kN;
 #pragma unroll
@@ -132,13 +152,13 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
         im[m] = (double)sbfe(wb[lane + 64 * m + kN2], shift, bgbit);
       }
       // P1: forward transform; the spectrum stays in this wave's tile, slot-major: [s][lane]
-      fft_forward(re, im, tw, mytile, lane);
+      if (!(TFHE_ABL_LAT & 8)) fft_forward(re, im, tw, mytile, lane);
       wave_lds_sync();  // the transform's last tile reads are done
 #pragma unroll
       for (int s = 0; s < 8; ++s) mytile[s * 64 + lane] = make_double2(re[s], im[s]);
     }
-    __syncthreads();
-    {
+    lds_barrier();
+    if (!(TFHE_ABL_LAT & 32)) {
       // P2: slot `wave` of fa = sum_r spectrum_r * Ka_r, fb = sum_r spectrum_r * Kb_r, rows in the batch kernel's order
       double far, fai, fbr, fbi;
 #pragma unroll
@@ -154,15 +174,8 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
       }
       sums[wave * 64 + lane] = make_double2(far, fai);
       sums[kN2 + wave * 64 + lane] = make_double2(fbr, fbi);
-      // next step's key slots (clamped on the last step: a harmless re-read)
-      const uint32_t nxt = (uint32_t)(i + 1 < n ? i + 1 : i) * per_i_bytes + my_slot;
-#pragma unroll
-      for (int r = 0; r < W; ++r) {
-        va[r] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)r * (2u * kN2 * 16u));
-        vb[r] = ldkey(bsk_rsrc, lane_off, nxt + (uint32_t)r * (2u * kN2 * 16u) + (uint32_t)(kN2 * 16));
-      }
     }
-    __syncthreads();
+    lds_barrier();
     if (wave < 2) {  // P3: wave 0 the a spectrum, wave 1 the b spectrum
       double f_re[8], f_im[8];
 #pragma unroll
@@ -171,7 +184,9 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
         f_re[s] = v.x;
         f_im[s] = v.y;
       }
-      fft_inverse(f_re, f_im, tw, tiles + (size_t)wave * kTileCplx, lane);
+      if (!(TFHE_ABL_LAT & 16)) fft_inverse(f_re, f_im, tw, tiles + (size_t)wave * kTileCplx, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      load_next_keys();
       uint32_t *q = acc + wave * kN;
 #pragma unroll
       for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
@@ -179,8 +194,10 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
         acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
         acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
       }
+    } else {
+      load_next_keys();  // the six waves without an inverse transform: AFTER the barrier, so that nobody waits for the issue
     }
-    __syncthreads();  // the accumulator is final for this step
+    lds_barrier();  // the accumulator is final for this step
   }
 
   if (A.out_trlwe) {

@@ -28,7 +28,8 @@
 #ifndef TFHE_ABL_TPB_DPP
 #define TFHE_ABL_TPB_DPP 0
 #endif
-#ifndef TFHE_ABL_LAT  // latency kernel: bit 0 no exchange of partial products, bit 1 no rotated reads / digits, bit 2 no update
+#ifndef TFHE_ABL_LAT  // latency kernels. wide: bit 0 no exchange of partial products, bit 1 no rotated reads / digits, bit 2 no update;
+                      // wide2: 8 no forward FFT, 16 no inverse FFT, 32 no MAC phase, 64 no key loads in the loop, 128 no digit preparation
 #define TFHE_ABL_LAT 0
 #endif
 #ifndef TFHE_ABL_KM_NOBARRIER  // matrix-core key switch without its per-step barrier (races: wrong results)
