@@ -6,6 +6,7 @@
 //   mode 2: ds_add_f64 into wave-private regions
 //   mode 3: ds_read_b128
 //   mode 4: ds_add_u32 into the same region
+//   modes 5-11: narrower / split stores and loads (is the 16-byte store the expensive form?)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -39,6 +40,13 @@ __global__ __launch_bounds__(512) void k(unsigned long long *out, int iters) {
       if (MODE == 2) asm volatile("ds_add_f64 %0, %1" ::"v"(priv + off + lane * 16 + (u >> 3) * 8), "v"(d[0]));
       if (MODE == 3) asm volatile("ds_read_b128 %0, %1" : "=v"(*(reinterpret_cast<__attribute__((ext_vector_type(4))) int *>(&d[2]))) : "v"(priv + off + lane * 16));
       if (MODE == 4) asm volatile("ds_add_u32 %0, %1" ::"v"(shared + off + lane * 4), "v"(lane));
+      if (MODE == 5) asm volatile("ds_write_b64 %0, %1" ::"v"(priv + off + lane * 8), "v"(d[0]));
+      if (MODE == 6) asm volatile("ds_write2_b64 %0, %1, %2 offset1:64" ::"v"(priv + off + lane * 8), "v"(d[0]), "v"(d[1]));
+      if (MODE == 7) asm volatile("ds_write_b32 %0, %1" ::"v"(priv + off + lane * 4), "v"(lane));
+      if (MODE == 8) asm volatile("ds_read_b64 %0, %1" : "=v"(d[2]) : "v"(priv + off + lane * 8));
+      if (MODE == 9) asm volatile("ds_read2_b64 %0, %1 offset1:64" : "=v"(*(reinterpret_cast<__attribute__((ext_vector_type(4))) int *>(&d[2]))) : "v"(priv + off + lane * 8));
+      if (MODE == 10) asm volatile("ds_write_b128 %0, %1" ::"v"(priv + off + ((lane & 31) * 32 + (lane >> 5) * 16)), "v"(*(reinterpret_cast<__attribute__((ext_vector_type(4))) int *>(&d[0]))));
+      if (MODE == 11) asm volatile("ds_write_b96 %0, %1" ::"v"(priv + off + lane * 16), "v"(*(reinterpret_cast<__attribute__((ext_vector_type(3))) int *>(&d[0]))));
     }
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -69,5 +77,12 @@ int main() {
   run<2>("ds_add_f64, wave-private", d);
   run<3>("ds_read_b128", d);
   run<4>("ds_add_u32, same region", d);
+  run<5>("ds_write_b64", d);
+  run<6>("ds_write2_b64 (2 x 8 B, 512 B apart)", d);
+  run<7>("ds_write_b32", d);
+  run<8>("ds_read_b64", d);
+  run<9>("ds_read2_b64 (2 x 8 B, 512 B apart)", d);
+  run<10>("ds_write_b128, lanes l / l+32 adjacent", d);
+  run<11>("ds_write_b96", d);
   return 0;
 }

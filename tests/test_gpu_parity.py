@@ -829,8 +829,9 @@ def test_pinned_host_buffers_run_in_place(O, eng128, keys128):
 
 
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
-    """Batches <= #CUs go through the 2l-waves-per-ciphertext latency kernel, larger ones through the
-    one-wave-per-ciphertext batch kernel: both must give the oracle's bits, for every output form."""
+    """Batches <= #CUs go through a latency kernel -- eight waves per ciphertext (blind_rotate_wide.hpp, the default)
+    or one wave per decomposition row (TFHE_HIP_BR_WIDE2=0) -- larger ones through the one-wave-per-ciphertext batch
+    kernel: all three must give the oracle's bits, for every output form."""
     import rs_tfhe_amd as R
 
     sk, ck = keys128
@@ -840,18 +841,51 @@ def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
     B = rng.integers(0, 2, 40).astype(bool)
     ca, cb = sk.encrypt_bool(A, 4600), sk.encrypt_bool(B, 4601)
     outs = {}
-    for wide in ("1", "0"):
+    for wide, wide2 in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("TFHE_HIP_BR_WIDE", wide)
+        monkeypatch.setenv("TFHE_HIP_BR_WIDE2", wide2)
         eng = R.Engine(pk.params, 0)
         eng.load_cloud_key(pk)
-        outs[wide] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
-                      eng.batch_bootstrap(ca[:5], keyswitch=False), eng.batch_gates_mixed(np.arange(40, dtype=np.uint8) % 10, ca, cb))
+        outs[wide + wide2] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
+                              eng.batch_bootstrap(ca[:5], keyswitch=False),
+                              eng.batch_gates_mixed(np.arange(40, dtype=np.uint8) % 10, ca, cb))
         eng.close()
-    for x, y in zip(outs["1"], outs["0"]):
-        assert np.array_equal(x, y)
-    assert np.array_equal(outs["1"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
-    assert np.array_equal(outs["1"][1], O.batch_blind_rotate(ck, ca[:5]))
-    assert np.array_equal(outs["1"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+    for other in ("10", "01"):
+        for x, y in zip(outs["11"], outs[other]):
+            assert np.array_equal(x, y), other
+    assert np.array_equal(outs["11"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
+    assert np.array_equal(outs["11"][1], O.batch_blind_rotate(ck, ca[:5]))
+    assert np.array_equal(outs["11"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("setname", ["SECURITY_UINT4", "SECURITY_UINT1", "SECURITY_UINT3"])
+def test_latency_kernels_same_bits_as_batch_kernel_inexact_sets(O, setname, monkeypatch):
+    """Where the f64 products are NOT exact (bgbit = 22 / 15) the result depends on the order of the floating-point
+    operations: the eight-wave latency kernel keeps the batch kernel's row order and FMA sequence, so a ciphertext's
+    bits do not depend on the size of the batch it arrives in (l = 1, 2 and 1)."""
+    import rs_tfhe_amd as R
+
+    sk, ck = oracle_keys(O, getattr(O, setname), seed=77)
+    pk = _cloud_key(ck)
+    m = 4
+    msgs = 1 + np.arange(12) % 3
+    cts = sk.encrypt_lwe_message(msgs, m, seed=7700)
+    outs = {}
+    for wide, wide2 in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("TFHE_HIP_BR_WIDE", wide)
+        monkeypatch.setenv("TFHE_HIP_BR_WIDE2", wide2)
+        eng = R.Engine(pk.params, 0)
+        eng.load_cloud_key(pk)
+        outs[wide + wide2] = (eng.batch_blind_rotate(cts), eng.batch_bootstrap(cts, keyswitch=True))
+        eng.close()
+    for x, y in zip(outs["11"], outs["01"]):
+        assert np.array_equal(x, y), setname
+    # The round-1/2 latency kernel (one wave per row) adds ROUNDED partial products instead.  At these widths one LSB of
+    # floating-point noise in a digit moves the mask by a whole (random) key element, so its ciphertexts are different
+    # encryptions of the same phase (the comparison test_pbs_uint4 makes against the oracle): check what they decrypt to.
+    for k in outs:  # phases 1/8, 1/4, 3/8 are all in the positive half: the sign test vector gives +1/8 = true
+        assert sk.decrypt_bool(outs[k][1]).all(), (setname, k)
 
 
 # ---- mixed-gate batches and levelised circuits ---------------------------------------------
