@@ -23,7 +23,7 @@ def child(wide_max, ks_split_max):
     eng = R.Engine(P, 0)
     eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2)
     dev = torch.device("cuda", 0)
-    for B in (1, 64, 256, 384, 512, 768, 1024, 1536, 2048, 4096, 8192):
+    for B in (1, 64, 256, 257, 512, 513, 768, 769, 1024, 1536, 2048):
         bits = np.random.default_rng(B).integers(0, 2, B).astype(bool)
         c = torch.from_numpy(sk.encrypt_bool(bits, seed=3).view(np.int32)).to(dev)
         o = torch.empty_like(c)

@@ -714,11 +714,14 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
-  ctx->wide_max = 2 * (size_t)ctx->num_cus;      // measured crossover vs the batch kernel: ~640 ciphertexts
   // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
   ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_BR_WIDE2")) ctx->br_wide2 = atoi(env) != 0;
+  // crossover vs the batch kernel (7.0 ms for anything up to 1,024 ciphertexts at 128 bit): the eight-wave form takes
+  // 2.2 / 4.5 / 6.6 / 8.5 ms for 1 / 2 / 3 / 4 rounds of one workgroup per CU, the six-wave form 3.0 / 6.1 / 9.1
+  // (profiles/exp/logs/r3o_crossover.log, r2q_crossover_latency_vs_batch.log)
+  ctx->wide_max = (ctx->br_wide2 ? 3 : 2) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
