@@ -315,7 +315,7 @@ def main():
     import hashlib
 
     hsrc = hashlib.sha256()
-    for name in ("blind_rotate.hpp", "experiment.hpp", "fft512.hpp", "key_switch.hpp", "key_switch_mfma.hpp", "keygen.hpp"):
+    for name in ("blind_rotate.hpp", "blind_rotate_wide.hpp", "experiment.hpp", "fft512.hpp", "key_switch.hpp", "key_switch_mfma.hpp", "keygen.hpp"):
         hsrc.update(name.encode())  # device code only (the same list as profiles/pmc_roofline.py)
         hsrc.update(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", name), "rb").read())
     csrc_sha = hsrc.hexdigest()[:16]

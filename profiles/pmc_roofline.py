@@ -68,7 +68,7 @@ def kernel_entry(sub):
     return e
 
 
-KERNEL_SOURCES = ("blind_rotate.hpp", "experiment.hpp", "fft512.hpp", "key_switch.hpp", "key_switch_mfma.hpp", "keygen.hpp")
+KERNEL_SOURCES = ("blind_rotate.hpp", "blind_rotate_wide.hpp", "experiment.hpp", "fft512.hpp", "key_switch.hpp", "key_switch_mfma.hpp", "keygen.hpp")
 
 
 def source_stamp():
