@@ -109,7 +109,8 @@ const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx);
  * So a call names its key by the handle it passes; calls under different keys of one context may come from
  * different threads (they serialise on the parent like any two calls on one context) and cost no second set of
  * scratch buffers, streams or twiddle tables.  tfhe_hip_ctx_destroy(view) drains the parent's queued work and
- * frees only the view's key; destroy every view before its parent.  tfhe_hip_last_error(view) is the parent's. */
+ * frees only the view's key; destroy every view before its parent (a parent destroyed first stays alive, unusable
+ * through its own handle, until its last view is destroyed).  tfhe_hip_last_error(view) is the parent's. */
 int tfhe_hip_key_create(tfhe_hip_ctx *ctx, tfhe_hip_ctx **key_view);
 /* The context a key view runs on (the handle itself for a plain context). */
 tfhe_hip_ctx *tfhe_hip_key_parent(tfhe_hip_ctx *key_view);

@@ -65,6 +65,7 @@ struct tfhe_hip_ctx {
   KeyState *K = &own;            // the key of the call in progress (bound by ENTER under the mutex)
   tfhe_hip_ctx *parent = nullptr;  // non-null: this handle is a key view of `parent` (only P, own, parent are used)
   int views = 0;                 // live key views of this context
+  bool dying = false;            // destroyed while views were alive: the last view to go frees the context
   double2 *d_tw = nullptr;
   DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out;  // scratch / host-API staging
   PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
@@ -760,14 +761,27 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   if (!ctx) return;
   if (ctx->parent) {  // a key view: drain the work that may still read its key, free the key, leave the parent alone
     tfhe_hip_ctx *base = ctx->parent;
-    std::lock_guard<std::mutex> lk(base->mu);
-    DeviceGuard dg(base->device);
-    if (base->scratch_owned && base->scratch_owner != base->stream) (void)hipStreamSynchronize(base->scratch_owner);
-    if (base->stream) (void)hipStreamSynchronize(base->stream);
-    free_key(ctx->own);
-    --base->views;
-    delete ctx;
+    bool last_of_dying = false;
+    {
+      std::lock_guard<std::mutex> lk(base->mu);
+      DeviceGuard dg(base->device);
+      if (base->scratch_owned && base->scratch_owner != base->stream) (void)hipStreamSynchronize(base->scratch_owner);
+      if (base->stream) (void)hipStreamSynchronize(base->stream);
+      free_key(ctx->own);
+      last_of_dying = --base->views == 0 && base->dying;
+      delete ctx;
+    }
+    if (last_of_dying) tfhe_hip_ctx_destroy(base);  // the parent was destroyed first: it has waited for its views
     return;
+  }
+  {
+    // Destroyed before its views (the header asks for the opposite order): the views still run on this context's
+    // stream, scratch and mutex, so keep it alive until the last of them goes.
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->views > 0) {
+      ctx->dying = true;
+      return;
+    }
   }
   DeviceGuard dg(ctx->device);
   if (ctx->scratch_owned && ctx->scratch_owner != ctx->stream) (void)hipStreamSynchronize(ctx->scratch_owner);

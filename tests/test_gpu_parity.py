@@ -737,6 +737,14 @@ def test_key_views_several_keys_on_one_context(O, eng128, keys128):
     v2.close()
     assert np.array_equal(v1.batch_gate(O.GATE_XOR, *in1), want1)  # closing one view leaves the others alone
     v1.close()
+    # wrong destroy order (parent before its view): the context stays alive until its last view goes
+    par = R.Engine(R.params.SECURITY_128_BIT, 0)
+    orphan = par.new_key_view()
+    orphan.load_cloud_key(pk2)
+    par._lib.tfhe_hip_ctx_destroy(par._ctx)
+    par._ctx, par._views = None, []
+    assert np.array_equal(orphan.batch_gate(O.GATE_XOR, *in2), want2)
+    orphan.close()
     # the same through a pool: two keys on the members of one pool (two contexts on this GPU)
     pool = R.Pool(R.params.SECURITY_128_BIT, [0, 0])
     pool.load_cloud_key(_cloud_key(ck1))
