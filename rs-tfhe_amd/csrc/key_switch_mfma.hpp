@@ -173,6 +173,9 @@ struct KmPos {
 // count rounded up to kKmRows rows (rows past count are computed and dropped).  out must be zero on entry: the four
 // byte planes (blockIdx.z) are merged with integer atomics (u32 addition commutes: same bits in any arrival order).
 // NT = tiles of the widest column block; a block with NT-1 tiles skips the last tile (wave-uniform branch).
+#ifndef TFHE_KM_XCD
+#define TFHE_KM_XCD 1
+#endif
 template <int NT>
 __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint32_t *__restrict__ lv1,        // [count][N+1]
                                                                        const unsigned char *__restrict__ ksk8,  // k_ksk_planes layout
@@ -189,8 +192,18 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)km_smem;
   const uint32_t off_ab = (uint32_t)(kKmSlots * SLOT) + (uint32_t)wave * 2u * kKmAbBytes;
   const uint32_t off_dump = (uint32_t)(kKmSlots * SLOT) + (uint32_t)(WAVES * 2 * kKmAbBytes) + (uint32_t)wave * 256u;
+#if TFHE_KM_XCD
+  // Workgroups are handed to the 8 XCDs round-robin in dispatch order (x fastest).  With 2 column blocks x 4 planes =
+  // 8 (plane, column block) streams, giving workgroup `lin` stream lin % 8 puts each stream on ONE XCD: that XCD's L2
+  // then holds one stream's window (all its row blocks walk K together) instead of a window of all eight.
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned combos = gridDim.y * gridDim.z, combo = lin % combos;
+  const size_t row0 = (size_t)(lin / combos) * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
+  const int cb = (int)(combo % gridDim.y), plane = (int)(combo / gridDim.y);  // one byte plane per workgroup
+#else
   const size_t row0 = (size_t)blockIdx.x * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
   const int cb = blockIdx.y, plane = blockIdx.z;  // one byte plane per workgroup: no epilogue inside the K loop
+#endif
   const int nt_blk = ks_mfma_block_tiles(n, cb), tile0 = ks_mfma_block_first(n, cb);
   const bool full = nt_blk == NT;  // wave-uniform
   const int spb = 2 * t, S = 64 * spb;  // steps per block, per plane

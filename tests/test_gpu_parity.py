@@ -609,7 +609,13 @@ def test_soak_gates_vs_cpu_path_128bit(O, eng128, keys128):
     assert np.array_equal(sk.decrypt_bool(got), ~(A & B))
     ra = rng.integers(0, 2**32, (rand, 701), dtype=np.uint64).astype(np.uint32)  # not encryptions of anything
     rb = rng.integers(0, 2**32, (rand, 701), dtype=np.uint64).astype(np.uint32)
-    bad += int((eng128.batch_gate(O.GATE_XOR, ra, rb) != O.batch_gate(ck, O.GATE_XOR, ra, rb)).any(axis=1).sum())
+    rx = eng128.batch_gate(O.GATE_XOR, ra, rb)
+    bad += int((rx != O.batch_gate(ck, O.GATE_XOR, ra, rb)).any(axis=1).sum())
+    # the same random words in pieces small enough for the latency kernels (<= 3 x #CUs): same bits as the batch kernels
+    lo = 0
+    for piece in (1, 37, 250, 700):
+        bad += int((eng128.batch_gate(O.GATE_XOR, ra[lo:lo + piece], rb[lo:lo + piece]) != rx[lo:lo + piece]).any(axis=1).sum())
+        lo += piece
     assert bad == 0, f"{bad} ciphertexts differ from the CPU path"
 
 
