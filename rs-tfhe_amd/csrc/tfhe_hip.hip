@@ -83,6 +83,7 @@ struct tfhe_hip_ctx {
   bool br_wide = true;      // small batches use the latency kernels
   bool br_wide2 = true;     // ... in their eight-wave form (blind_rotate_wide.hpp); false: one wave per row (round 1-2)
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
+  size_t pair_lo = 0, pair_max = 0;  // ... two ciphertexts per eight-wave workgroup (k_blind_rotate_pair) for pair_lo < count <= pair_max
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
@@ -221,6 +222,15 @@ br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
   }
 }
 
+br_kernel_t br_pair_kernel(const tfhe_hip_ctx *ctx) {
+  const bool f = ctx->fast_round;
+  switch (ctx->P.l) {
+    case 1: return f ? k_blind_rotate_pair<1, true> : k_blind_rotate_pair<1, false>;
+    case 2: return f ? k_blind_rotate_pair<2, true> : k_blind_rotate_pair<2, false>;
+    default: return f ? k_blind_rotate_pair<3, true> : k_blind_rotate_pair<3, false>;
+  }
+}
+
 br_kernel_t br_wide_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
   if (ctx->br_wide2) switch (ctx->P.l) {
@@ -279,7 +289,20 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (out_ext2 && ctx->P.n > kN)
     return fail(ctx, TFHE_HIP_EINVAL, "bootstrap without key switch needs n <= N (sample_extract_index_2)");
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
-  // small batches: one workgroup of 2l waves per ciphertext (latency kernel)
+  // Small batches (latency kernels).  Eight-wave form, N = #CUs: up to N ciphertexts one workgroup each (2.2 ms at
+  // 128 bit); N < count <= 2N two ciphertexts per workgroup, half a step apart (3.6 ms; two rounds of the former take
+  // 4.5); up to 3N three rounds of the former (6.5; the pair kernel needs 7.3, the batch kernel 7.0 for anything up to
+  // 4N) -- profiles/exp/logs/r3x_pair_kernel.log.  wide_max / pair_lo / pair_max hold those bounds.
+  const bool pair = ctx->br_wide && ctx->br_wide2 && count > ctx->pair_lo && count <= ctx->pair_max;
+  if (pair) {
+    CHK(record_begin(ctx, s, ctx->ev_br));
+    hipLaunchKernelGGL(br_pair_kernel(ctx), dim3((unsigned)((count + 1) / 2)), dim3(64u * kPairWaves),
+                       blind_rotate_pair_lds_bytes(ctx->P.n), s, A);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_br));
+    ctx->bootstraps += count;
+    return TFHE_HIP_OK;
+  }
   if (ctx->br_wide && count <= ctx->wide_max) {
     br_kernel_t kern = br_wide_kernel(ctx);
     const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l) : blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
@@ -724,6 +747,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   // (profiles/exp/logs/r3o_crossover.log, r2q_crossover_latency_vs_batch.log)
   ctx->wide_max = (ctx->br_wide2 ? 3 : 2) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
+  ctx->pair_lo = (size_t)ctx->num_cus;
+  ctx->pair_max = 2 * (size_t)ctx->num_cus;
+  if (const char *env = getenv("TFHE_HIP_PAIR_LO")) ctx->pair_lo = (size_t)atol(env);
+  if (const char *env = getenv("TFHE_HIP_PAIR_MAX")) ctx->pair_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
   // dynamic LDS above the 64 KiB default, declared once per context for the kernels of this parameter set
@@ -734,6 +761,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
       return bail("hipFuncSetAttribute(k_blind_rotate)", e);
     if ((e = hipFuncSetAttribute((const void *)br_wide_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate_wide)", e);
+    if (blind_rotate_pair_lds_bytes(p->n) > 160 * 1024) ctx->pair_max = 0;  // (n > 1,900: no parameter set)
+    else if ((e = hipFuncSetAttribute((const void *)br_pair_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)blind_rotate_pair_lds_bytes(p->n))) != hipSuccess)
+      return bail("hipFuncSetAttribute(k_blind_rotate_pair)", e);
   }
   std::vector<double2> tw;
   make_twiddles(tw);

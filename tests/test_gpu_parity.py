@@ -842,42 +842,79 @@ def test_pinned_host_buffers_run_in_place(O, eng128, keys128):
     pool.close()
 
 
+# the four blind-rotation kernels by environment: eight waves per ciphertext (default up to #CUs), one wave per
+# decomposition row (round 1-2), two ciphertexts per eight-wave workgroup (default for #CUs < count <= 2 #CUs; forced
+# at every count here), the batch kernel
+BR_KERNEL_ENVS = {
+    "wide2": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "1", "TFHE_HIP_PAIR_MAX": "0"},
+    "wide": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "0"},
+    "pair": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "1", "TFHE_HIP_PAIR_LO": "0", "TFHE_HIP_PAIR_MAX": "1000000"},
+    "batch": {"TFHE_HIP_BR_WIDE": "0"},
+}
+
+
+def _with_br_kernel(monkeypatch, name):
+    for k in ("TFHE_HIP_BR_WIDE", "TFHE_HIP_BR_WIDE2", "TFHE_HIP_PAIR_LO", "TFHE_HIP_PAIR_MAX"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in BR_KERNEL_ENVS[name].items():
+        monkeypatch.setenv(k, v)
+
+
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
-    """Batches <= #CUs go through a latency kernel -- eight waves per ciphertext (blind_rotate_wide.hpp, the default)
-    or one wave per decomposition row (TFHE_HIP_BR_WIDE2=0) -- larger ones through the one-wave-per-ciphertext batch
-    kernel: all three must give the oracle's bits, for every output form."""
+    """Small batches go through the latency kernels -- eight waves per ciphertext (blind_rotate_wide.hpp), two
+    ciphertexts per eight-wave workgroup (k_blind_rotate_pair, odd counts included), or the round-2 form with one
+    wave per decomposition row -- larger ones through the one-wave-per-ciphertext batch kernel: all four must give
+    the oracle's bits, for every output form."""
     import rs_tfhe_amd as R
 
     sk, ck = keys128
     pk = _cloud_key(ck)
     rng = np.random.default_rng(46)
-    A = rng.integers(0, 2, 40).astype(bool)
-    B = rng.integers(0, 2, 40).astype(bool)
+    A = rng.integers(0, 2, 41).astype(bool)
+    B = rng.integers(0, 2, 41).astype(bool)
     ca, cb = sk.encrypt_bool(A, 4600), sk.encrypt_bool(B, 4601)
     outs = {}
-    for wide, wide2 in (("1", "1"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("TFHE_HIP_BR_WIDE", wide)
-        monkeypatch.setenv("TFHE_HIP_BR_WIDE2", wide2)
+    for name in BR_KERNEL_ENVS:
+        _with_br_kernel(monkeypatch, name)
         eng = R.Engine(pk.params, 0)
         eng.load_cloud_key(pk)
-        outs[wide + wide2] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
-                              eng.batch_bootstrap(ca[:5], keyswitch=False),
-                              eng.batch_gates_mixed(np.arange(40, dtype=np.uint8) % 10, ca, cb))
+        outs[name] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
+                      eng.batch_bootstrap(ca[:5], keyswitch=False),
+                      eng.batch_gates_mixed(np.arange(41, dtype=np.uint8) % 10, ca, cb),
+                      eng.batch_gate(O.GATE_XOR, ca[:1], cb[:1]))
         eng.close()
-    for other in ("10", "01"):
-        for x, y in zip(outs["11"], outs[other]):
+    for other in ("wide", "pair", "batch"):
+        for x, y in zip(outs["wide2"], outs[other]):
             assert np.array_equal(x, y), other
-    assert np.array_equal(outs["11"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
-    assert np.array_equal(outs["11"][1], O.batch_blind_rotate(ck, ca[:5]))
-    assert np.array_equal(outs["11"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+    assert np.array_equal(outs["wide2"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
+    assert np.array_equal(outs["wide2"][1], O.batch_blind_rotate(ck, ca[:5]))
+    assert np.array_equal(outs["wide2"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+
+
+def test_pair_kernel_is_the_default_between_one_and_two_per_cu(O, keys128):
+    """#CUs < count <= 2 #CUs (257 ... 512 on an MI355X) takes k_blind_rotate_pair by default: an odd count in that
+    range against the CPU path."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    count = 301
+    rng = np.random.default_rng(461)
+    A, B = rng.integers(0, 2, count).astype(bool), rng.integers(0, 2, count).astype(bool)
+    ca, cb = sk.encrypt_bool(A, 4610), sk.encrypt_bool(B, 4611)
+    got = eng.batch_gate(O.GATE_NOR, ca, cb)
+    assert np.array_equal(got, O.batch_gate(ck, O.GATE_NOR, ca, cb))
+    assert np.array_equal(sk.decrypt_bool(got), ~(A | B))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("setname", ["SECURITY_UINT4", "SECURITY_UINT1", "SECURITY_UINT3"])
 def test_latency_kernels_same_bits_as_batch_kernel_inexact_sets(O, setname, monkeypatch):
     """Where the f64 products are NOT exact (bgbit = 22 / 15) the result depends on the order of the floating-point
-    operations: the eight-wave latency kernel keeps the batch kernel's row order and FMA sequence, so a ciphertext's
-    bits do not depend on the size of the batch it arrives in (l = 1, 2 and 1)."""
+    operations: the eight-wave latency kernels (one and two ciphertexts per workgroup) keep the batch kernel's row order
+    and FMA sequence, so a ciphertext's bits do not depend on the size of the batch it arrives in (l = 1, 2 and 1)."""
     import rs_tfhe_amd as R
 
     sk, ck = oracle_keys(O, getattr(O, setname), seed=77)
@@ -886,15 +923,15 @@ def test_latency_kernels_same_bits_as_batch_kernel_inexact_sets(O, setname, monk
     msgs = 1 + np.arange(12) % 3
     cts = sk.encrypt_lwe_message(msgs, m, seed=7700)
     outs = {}
-    for wide, wide2 in (("1", "1"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("TFHE_HIP_BR_WIDE", wide)
-        monkeypatch.setenv("TFHE_HIP_BR_WIDE2", wide2)
+    for name in BR_KERNEL_ENVS:
+        _with_br_kernel(monkeypatch, name)
         eng = R.Engine(pk.params, 0)
         eng.load_cloud_key(pk)
-        outs[wide + wide2] = (eng.batch_blind_rotate(cts), eng.batch_bootstrap(cts, keyswitch=True))
+        outs[name] = (eng.batch_blind_rotate(cts[:11]), eng.batch_bootstrap(cts[:11], keyswitch=True))
         eng.close()
-    for x, y in zip(outs["11"], outs["01"]):
-        assert np.array_equal(x, y), setname
+    for other in ("pair", "batch"):
+        for x, y in zip(outs["wide2"], outs[other]):
+            assert np.array_equal(x, y), (setname, other)
     # The round-1/2 latency kernel (one wave per row) adds ROUNDED partial products instead.  At these widths one LSB of
     # floating-point noise in a digit moves the mask by a whole (random) key element, so its ciphertexts are different
     # encryptions of the same phase (the comparison test_pbs_uint4 makes against the oracle): check what they decrypt to.
