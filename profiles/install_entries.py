@@ -15,7 +15,9 @@ P = os.path.join(ROOT, "profiles")
 path = os.path.join(P, "pmc_roofline.json")
 entries = json.load(open(path))
 for tag in sys.argv[1:]:
-    for suffix in ("_kernel_stats.csv", "_pmc.csv"):
+    for suffix in ("_kernel_stats.csv", "_pmc.csv", "_trace_bench.json"):
+        if suffix == "_trace_bench.json" and not os.path.exists(os.path.join(G, tag + suffix)):
+            continue
         shutil.copy(os.path.join(G, tag + suffix), os.path.join(P, tag + suffix))
     new = json.load(open(os.path.join(G, tag + "_pmc_roofline.json")))
     entries = [e for e in entries if e.get("tag") != tag] + [new]
