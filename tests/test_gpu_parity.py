@@ -619,6 +619,46 @@ def test_soak_gates_vs_cpu_path_128bit(O, eng128, keys128):
     assert bad == 0, f"{bad} ciphertexts differ from the CPU path"
 
 
+def test_contexts_views_and_pools_give_their_memory_back(O, keys128):
+    """Create / use / destroy cycles of contexts, key views and pools (host API, device API, every batch-size regime
+    so that all scratch buffers get allocated): device memory in use returns to where it started."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    A = np.resize(np.array([1, 0, 1, 1, 0], bool), 1100)
+    ca, cb = sk.encrypt_bool(A, 7301), sk.encrypt_bool(~A, 7302)
+
+    def cycle():
+        eng = R.Engine(pk.params, 0)
+        eng.load_cloud_key(pk)
+        view = eng.new_key_view()
+        view.load_cloud_key(pk)
+        for count in (1, 300, 1100):  # one and two ciphertexts per workgroup, batch kernel + matrix-core key switch
+            eng.batch_gate(O.GATE_NAND, ca[:count], cb[:count])
+        view.batch_gate(O.GATE_XOR, ca[:5], cb[:5])
+        view.close()
+        eng.close()
+        pool = R.Pool(pk.params, [0, 0])
+        pool.load_cloud_key(pk)
+        pv = pool.new_key_view()
+        pv.load_cloud_key(pk)
+        pv.batch_gate(O.GATE_AND, ca[:600], cb[:600])
+        pv.close()
+        pool.close()
+
+    cycle()  # first use pays for lazily created runtime state (streams, module load)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(0)
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free0 - free1 < 8 << 20, f"{(free0 - free1) >> 20} MiB not returned after three create/destroy cycles"
+
+
 def test_bad_gate_code_on_the_device_is_reported(O, eng128, keys128):
     """tfhe_hip_batch_gates_mixed_dev cannot read the codes on the host: a code outside tfhe_hip_gate is treated as
     COPY by the kernel AND raises a device-side flag that the next tfhe_hip_synchronize returns as EINVAL (once).
