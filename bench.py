@@ -105,7 +105,7 @@ def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch):
     measured i8 ceiling (3,944 TOPS, v_mfma_i32_16x16x64_i8; 32x32x32: 4,404), with the clock the kernel sustained
     (the matrix pipes are current-limited: 1.6-2.4 GHz depending on operand toggling,
     profiles/exp/logs/r3d_ubench_mfma.log).  Other sets: the LDS-ring kernels, instruction-issue bound."""
-    mfma = P.basebit == 2 and batch >= 512 and os.environ.get("TFHE_HIP_KS_MFMA", "1") != "0"
+    mfma = P.basebit == 2 and batch >= 64 and os.environ.get("TFHE_HIP_KS_MFMA", "1") != "0"
     out = {"avg_launch_ms": round(ks_ms, 3)}
     if mfma and ks_ms > 0:
         cols = -(-(P.n + 1) // 32) * 32

@@ -181,7 +181,8 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
                                                                        const unsigned char *__restrict__ ksk8,  // k_ksk_planes layout
                                                                        int n, int t, uint32_t *__restrict__ out,  // [count][n+1]
                                                                        size_t count,
-                                                                       unsigned long long *clk) {  // optional [2]: += shader cycles, += constant-rate ticks
+                                                                       unsigned long long *clk,  // optional [2]: += shader cycles, += constant-rate ticks
+                                                                       int ksplit) {  // 1, 2, 4, 8 or 16: the walk over the 64 coefficient blocks is cut into this many workgroups
   constexpr int N = 1024, D = kKmAhead, WAVES = kKmWaves, R = kKmFrags;
   constexpr int TPW = ks_mfma_tpw(NT), SLOT = ks_mfma_slot_bytes(NT), OPS = TPW + R;
   const unsigned long long clk0 = clk ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -197,13 +198,18 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
   // 8 (plane, column block) streams, giving workgroup `lin` stream lin % 8 puts each stream on ONE XCD: that XCD's L2
   // then holds one stream's window (all its row blocks walk K together) instead of a window of all eight.
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const unsigned combos = gridDim.y * gridDim.z, combo = lin % combos;
-  const size_t row0 = (size_t)(lin / combos) * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
+  const unsigned combos = gridDim.y * gridDim.z, combo = lin % combos, rest = lin / combos;
   const int cb = (int)(combo % gridDim.y), plane = (int)(combo / gridDim.y);  // one byte plane per workgroup
 #else
-  const size_t row0 = (size_t)blockIdx.x * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
+  const unsigned rest = blockIdx.x;
   const int cb = blockIdx.y, plane = blockIdx.z;  // one byte plane per workgroup: no epilogue inside the K loop
 #endif
+  // grid.x = row blocks x K chunks: small batches cut the walk over K so that the whole chip works on them (the
+  // chunks, like the planes, meet in the output through integer atomics)
+  const unsigned n_rb = gridDim.x / (unsigned)ksplit;
+  const int kchunk = (int)(rest / n_rb);                 // this workgroup's K chunk
+  const int blk0 = kchunk * (64 / ksplit);               // its first coefficient block (even: the a_bar double buffer starts at 0)
+  const size_t row0 = (size_t)(rest % n_rb) * kKmRows + (size_t)wave * (32 * R);  // this wave's rows
   const int nt_blk = ks_mfma_block_tiles(n, cb), tile0 = ks_mfma_block_first(n, cb);
   const bool full = nt_blk == NT;  // wave-uniform
   const int spb = 2 * t, S = 64 * spb;  // steps per block, per plane
@@ -224,6 +230,9 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
     koff[i] = (uint32_t)(tile < nt_blk ? tile : nt_blk - 1) * 1024u + v16;
   }
   const uint32_t kstride = (uint32_t)nt_blk * 1024u;
+  const int steps = S / ksplit;  // K-steps of this workgroup: 64 / ksplit blocks
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) koff[i] += (uint32_t)(blk0 * spb) * kstride;
   auto dma_key = [&](uint32_t slot) {
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
   };
 
   // ---- prologue: a_bar block 0, key steps 0 .. D-1 ---------------------------------------------
-  for (int q = 0; q < kKmAbQ; ++q) km_dma4(v4, ab_row0 + (size_t)(4 * q) * (N + 1), lds_base + off_ab + (uint32_t)q * 256u);
+  for (int q = 0; q < kKmAbQ; ++q) km_dma4(v4, ab_row0 + (size_t)(4 * q) * (N + 1) + 16 * blk0, lds_base + off_ab + (uint32_t)q * 256u);
   for (int d = 0; d < D; ++d) dma_key(lds_base + (uint32_t)d * SLOT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
     return __builtin_bit_cast(km_i32x4, a);
   };
   auto make_a = [&](const KmPos &q, int f) -> km_i32x4 { return build_a(q, read_a(q, f)); };
-  KmPos cur{0, 0};
+  KmPos cur{blk0, 0};
   km_i32x4 A[R];
 #pragma unroll
   for (int f = 0; f < R; ++f) A[f] = make_a(cur, f);
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
   auto run = [&](auto full_c) {
     constexpr bool FULL = decltype(full_c)::value;  // every tile of the block exists (else the last one is skipped)
 #pragma unroll 1
-    for (int g = 0; g < S; ++g) {
+    for (int g = 0; g < steps; ++g) {
       const unsigned char *slot = km_smem + (uint32_t)(g % kKmSlots) * SLOT + v16;
       const unsigned char *slot_next = km_smem + (uint32_t)((g + 1) % kKmSlots) * SLOT + v16;
       km_i32x4 B[NT];
@@ -375,7 +384,7 @@ __global__ __launch_bounds__(64 * kKmWaves, 2) void k_key_switch_mfma(const uint
 #pragma unroll
       for (int c = 0; c < NT; ++c) {
         const bool col_ok = col_lane + 32 * c <= n && c < nt_blk;
-        const bool is_body = col_lane + 32 * c == n && plane == 0;
+        const bool is_body = col_lane + 32 * c == n && plane == 0 && kchunk == 0;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int er = 32 * f + (e & 3) + 8 * (e >> 2);

@@ -79,7 +79,8 @@ struct tfhe_hip_ctx {
   int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
   int ks_sliced_sets = 0;  // 0: accumulator sets per lane picked per launch (ks_sliced_pick_sets); else forced (24..40)
   int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
-  size_t ks_mfma_min = 512;  // smallest batch the matrix-core kernel takes (below: the split kernel)
+  size_t ks_mfma_min = 64;   // smallest batch the matrix-core kernel takes (below: the split kernel)
+  int ks_mfma_ksplit = 0;    // 0: K chunks per row block picked per launch; else forced (1, 2, 4, 8, 16)
   bool br_wide = true;      // small batches use the latency kernels
   bool br_wide2 = true;     // ... in their eight-wave form (blind_rotate_wide.hpp); false: one wave per row (round 1-2)
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
@@ -352,7 +353,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
 }
 
 // ---- base-4 key switch on the matrix cores (key_switch_mfma.hpp) -----------------------------------
-typedef void (*km_kernel_t)(const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t, unsigned long long *);
+typedef void (*km_kernel_t)(const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t, unsigned long long *, int);
 // instantiated tile counts of the widest column block (32 columns each): 1 .. kKmMaxTiles
 int ks_mfma_nt(int n) {
   const int need = ks_mfma_tiles(n);
@@ -409,13 +410,19 @@ int launch_key_switch_mfma(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1
     dst = (uint32_t *)ctx->ks_out.p;
   }
   HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
-  // one workgroup per (256 rows, column block, byte plane); consecutive workgroups walk the same key plane
+  // one workgroup per (128 rows, column block, byte plane, K chunk); consecutive workgroups walk the same key plane.
+  // Small batches have few row blocks: the walk over K is cut into up to 16 chunks so that there are about two
+  // workgroups per CU to run (a 256-ciphertext batch is 2 row blocks x 8 streams = 16 workgroups otherwise).
   const size_t rb = (count + kKmRows - 1) / kKmRows;
   const size_t lds = ks_mfma_lds_bytes(nt);
   const int tiles = ks_mfma_total_tiles(n);
-  hipLaunchKernelGGL(kern, dim3((unsigned)rb, (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks), 4), dim3(64 * kKmWaves), lds, s, lv1,
+  const unsigned ncb = (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks);
+  int ksplit = 1;
+  while (ksplit < 16 && rb * ncb * 4 * (size_t)ksplit < 2 * (size_t)ctx->num_cus) ksplit *= 2;
+  if (ctx->ks_mfma_ksplit) ksplit = ctx->ks_mfma_ksplit;
+  hipLaunchKernelGGL(kern, dim3((unsigned)rb * (unsigned)ksplit, ncb, 4), dim3(64 * kKmWaves), lds, s, lv1,
                      (const unsigned char *)ctx->K->d_ksk8, n, ctx->P.t, dst, count,
-                     ctx->profiling ? ctx->d_diag + 4 : nullptr);
+                     ctx->profiling ? ctx->d_diag + 4 : nullptr, ksplit);
   HIPCHK(ctx, hipGetLastError());
   if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
   return TFHE_HIP_OK;
@@ -428,9 +435,10 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
   dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
   CHK(record_begin(ctx, s, ctx->ev_ks));
-  // base-4 sets from 512 ciphertexts up: the matrix-core kernel (0.55-0.75 ms for anything up to 8,192 ciphertexts --
-  // one round of workgroups -- against 0.55 ms at 512 and 3.7 ms at 4,096 for the split kernel,
-  // profiles/exp/logs/r3k_ks_crossover.log)
+  // base-4 sets from 64 ciphertexts up: the matrix-core kernel, its walk over K cut into chunks while the batch is
+  // too small to fill the chip with row blocks (0.10 / 0.11 / 0.15 / 0.18 / 0.25 / 0.40 ms at 64 / 256 / 512 / 1,024 /
+  // 2,048 / 4,096 ciphertexts; the split kernel takes 0.12 / 0.33 / 0.55 / 0.97 / 1.8 / 3.6, the matrix-core kernel
+  // without chunks 0.42-0.49 throughout: profiles/exp/logs/r3_ks_splitk.log)
   if (ks_mfma_wanted(ctx, count)) {
     CHK(launch_key_switch_mfma(ctx, s, lv1, out, count));
     CHK(record_end(ctx, s, ctx->ev_ks));
@@ -738,6 +746,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
+  if (const char *env = getenv("TFHE_HIP_KS_MFMA_KSPLIT")) {
+    const int v = atoi(env);
+    ctx->ks_mfma_ksplit = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
+  }
   // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
   ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;

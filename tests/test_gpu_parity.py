@@ -181,11 +181,14 @@ def test_key_switch_bit_exact(O, eng128, keys128):
 
 
 @pytest.mark.parametrize("setname,env", [
-    ("SECURITY_128_BIT", {}),                                # default dispatch: LDS ring below 512, matrix cores from 512
+    ("SECURITY_128_BIT", {}),                                # default dispatch: LDS ring below 64, matrix cores (K in chunks) from 64
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0"}),         # k_key_switch_b4 (LDS ring, base 4) at every count
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0", "TFHE_HIP_KS_B4": "0"}),  # k_key_switch (generic, buffer loads)
     ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0", "TFHE_HIP_KS_SLICED": "2"}),  # k_key_switch_sliced forced at base 4
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<6> (int8 matrix cores), t = 9, blocks of 6,6,5,5 tiles
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<11> (int8 matrix cores), t = 9; K chunks picked per launch (16 ... 4 here)
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "1"}),   # ... the whole walk in one workgroup
+    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "2"}),   # ... in two
+    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "16"}),   # ... in sixteen, t = 7
     ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
     ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
     ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<6>, t = 8
