@@ -365,7 +365,10 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
                                                             const unsigned char *__restrict__ ksk,  // engine layout
                                                             int n, int basebit, int t,
                                                             uint32_t *__restrict__ out, size_t count) {
+  // gridDim.z = K chunks: small batches cut the walk over the N coefficients into that many workgroups, which meet
+  // in the (then zeroed) output through integer atomics -- u32 addition commutes: same bits in any arrival order
   constexpr int N = 1024, NS = kKsSlSlots, D = NS - 1, CTS = ks_sliced_cts(S);
+  const int kchunks = (int)gridDim.z, i_begin = (int)blockIdx.z * (N / kchunks), i_end = i_begin + N / kchunks;
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
   const uint32_t base = 1u << basebit;
@@ -404,12 +407,12 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
 #pragma unroll
   for (int a = 0; a < S; ++a) acc[a] = u32x4{0u, 0u, 0u, 0u};
 
+  uint32_t q = (uint32_t)i_begin * (uint32_t)t;
 #pragma unroll 1
-  for (uint32_t d = 0; d < (uint32_t)D; ++d) dma_group(d);
+  for (uint32_t d = 0; d < (uint32_t)D; ++d) dma_group(q + d);
 
-  uint32_t q = 0;
 #pragma unroll 1
-  for (int i0 = 0; i0 < N; i0 += IC) {
+  for (int i0 = i_begin; i0 < i_end; i0 += IC) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int idx = tid; idx < CTS * IC; idx += 256) {
@@ -468,8 +471,13 @@ __global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__res
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int x = (int)(col0 + c4 * 4u) + c;
-        if (x < n) o[x] = w[c];
-        if (x == n) o[x] = w[c] + lv1[ct * (N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+        if (kchunks == 1) {
+          if (x < n) o[x] = w[c];
+          if (x == n) o[x] = w[c] + lv1[ct * (N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+        } else if (x <= n) {
+          const uint32_t v = w[c] + ((x == n && blockIdx.z == 0) ? lv1[ct * (N + 1) + N] : 0u);
+          if (v) atomicAdd(&o[x], v);
+        }
       }
     }
   }

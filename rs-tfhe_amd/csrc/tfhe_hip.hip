@@ -81,6 +81,8 @@ struct tfhe_hip_ctx {
   int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
   size_t ks_mfma_min = 64;   // smallest batch the matrix-core kernel takes (below: the split kernel)
   int ks_mfma_ksplit = 0;    // 0: K chunks per row block picked per launch; else forced (1, 2, 4, 8, 16)
+  size_t ks_sl_chunk_min = 384;  // wider bases: smallest batch the column-sliced kernel takes (with K chunks; below: the split kernel)
+  int ks_sl_kchunks = 0;     // 0: K chunks of the column-sliced kernel picked per launch; else forced (1 ... 64, a power of two)
   bool br_wide = true;      // small batches use the latency kernels
   bool br_wide2 = true;     // ... in their eight-wave form (blind_rotate_wide.hpp); false: one wave per row (round 1-2)
   size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
@@ -444,7 +446,13 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
     CHK(record_end(ctx, s, ctx->ev_ks));
     return TFHE_HIP_OK;
   }
-  if (ctx->br_wide && count <= ctx->ks_split_max) {
+  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);  // at the default S; the launch re-derives it for the S it picks
+  const bool sliced_ok = (ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024;
+  // wider bases from 384 ciphertexts up: the column-sliced kernel with its walk over the coefficients cut into chunks
+  // (below; SECURITY_UINT4: 0.37 / 0.37 / 0.57 / 1.05 ms at 512 / 1,024 / 2,048 / 4,096 ciphertexts where the split
+  // kernel takes 0.46 / 0.85 / 1.62 / 3.42 and wins below: 0.27 vs 0.29 at 256 -- profiles/exp/logs/r3_ks_sl_chunks.log).
+  // Smaller batches, and whatever neither LDS kernel covers:
+  if (ctx->br_wide && count <= ctx->ks_split_max && !(sliced_ok && count >= ctx->ks_sl_chunk_min)) {
     // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
     const size_t kb = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
     HIPCHK(ctx, hipMemsetAsync(out, 0, count * (size_t)(n + 1) * 4, s));
@@ -457,15 +465,37 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
   const size_t b4_lds = ks_b4_lds_bytes(bd >> 6, kKsG);
   const bool b4_fits = b4_lds <= 64 * 1024;
-  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);  // at the default S; the launch re-derives it for the S it picks
-  if ((ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024) {
+  if (sliced_ok) {
     // accumulator sets per lane: whichever fills whole rounds of the machine (two workgroups per CU)
     const int slices = (n + 1 + 63) / 64, base = 1 << ctx->P.basebit;
     int sets = ks_sliced_pick_sets(count, slices, 2 * ctx->num_cus);
     if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
     if (ks_sliced_lds_bytes(base, sets) > 64 * 1024) sets = kKsSlSets;
     const size_t lds = ks_sliced_lds_bytes(base, sets);
-    dim3 sgrid((unsigned)((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)), (unsigned)slices);
+    // small batches have few ciphertext groups: the walk over the N coefficients is cut into up to 64 chunks (grid.z)
+    // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics
+    const size_t groups = (count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
+    int kchunks = 1;
+    if (ctx->br_wide)
+      while (kchunks < 64 && groups * (size_t)slices * (size_t)kchunks < 2 * (size_t)ctx->num_cus) kchunks *= 2;
+    if (ctx->ks_sl_kchunks) kchunks = ctx->ks_sl_kchunks;
+    uint32_t *dst = out;
+    bool host_out = false;
+    const size_t obytes = count * (size_t)(n + 1) * 4;
+    if (kchunks > 1) {  // atomics: host (pinned, zero-copy) outputs go through a device buffer, as for the matrix-core kernel
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, (const void *)out) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(ctx, TFHE_HIP_EINVAL, "key switch output is not GPU-addressable memory");
+      }
+      if (at.type == hipMemoryTypeHost) {
+        host_out = true;
+        CHK(ensure(ctx, ctx->ks_out, obytes));
+        dst = (uint32_t *)ctx->ks_out.p;
+      }
+      HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
+    }
+    dim3 sgrid((unsigned)groups, (unsigned)slices, (unsigned)kchunks);
     typedef void (*sl_kernel_t)(const uint32_t *, const unsigned char *, int, int, int, uint32_t *, size_t);
     sl_kernel_t kern = nullptr;
     const bool ic8 = ks_sliced_stage(base) == 8;
@@ -477,7 +507,11 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
       default: kern = ic8 ? k_key_switch_sliced<8, 32> : k_key_switch_sliced<16, 32>; break;
     }
     hipLaunchKernelGGL(kern, sgrid, dim3(256), lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n, ctx->P.basebit, ctx->P.t,
-                       out, count);
+                       dst, count);
+    if (host_out) {
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
+    }
   } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
     hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
                        ctx->P.t, out, count);
@@ -746,6 +780,11 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
+  if (const char *env = getenv("TFHE_HIP_KS_SL_CHUNK_MIN")) ctx->ks_sl_chunk_min = (size_t)atol(env);
+  if (const char *env = getenv("TFHE_HIP_KS_SL_KCHUNKS")) {
+    const int v = atoi(env);
+    ctx->ks_sl_kchunks = (v >= 1 && v <= 64 && (v & (v - 1)) == 0) ? v : 0;
+  }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_KSPLIT")) {
     const int v = atoi(env);
     ctx->ks_mfma_ksplit = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;

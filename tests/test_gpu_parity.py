@@ -192,7 +192,10 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
     ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
     ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<6>, t = 8
-    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32), sets per lane picked per launch
+    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32), sets per lane and K chunks picked per launch
+    ("SECURITY_UINT4", {"TFHE_HIP_KS_SL_KCHUNKS": "1"}),     # ... the whole walk in one workgroup (plain stores)
+    ("SECURITY_UINT4", {"TFHE_HIP_KS_SL_KCHUNKS": "64"}),    # ... in 64 chunks of 16 coefficients (= one a_bar stage)
+    ("SECURITY_UINT3", {"TFHE_HIP_KS_SL_KCHUNKS": "8"}),     # base 64 (8-coefficient stages), 8 chunks
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "36"}),   # ... forced to 36 sets (what a 65,536 batch picks) / 28 / 40
     ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "28"}),
     ("SECURITY_UINT2", {"TFHE_HIP_KS_SLICED_SETS": "40"}),
