@@ -294,26 +294,53 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
   // Small batches (latency kernels).  Eight-wave form, N = #CUs: up to N ciphertexts one workgroup each (2.2 ms at
   // 128 bit); N < count <= 2N two ciphertexts per workgroup, half a step apart (3.6 ms; two rounds of the former take
-  // 4.5); up to 3N three rounds of the former (6.5; the pair kernel needs 7.3, the batch kernel 7.0 for anything up to
-  // 4N) -- profiles/exp/logs/r3x_pair_kernel.log.  wide_max / pair_lo / pair_max hold those bounds.
-  const bool pair = ctx->br_wide && ctx->br_wide2 && count > ctx->pair_lo && count <= ctx->pair_max;
-  if (pair) {
+  // 4.5); up to 3N the first 2N as pairs and the rest as singles (5.8; three rounds of singles 6.4, pairs alone 7.3,
+  // the batch kernel 7.0 for anything up to 4N) -- profiles/exp/logs/r3x_pair_kernel.log.  wide_max / pair_lo /
+  // pair_max hold those bounds.
+  // ciphertexts [done, done + m) of this call as a launch of their own
+  auto part = [&](size_t done, size_t m) {
+    BlindRotateArgs S = A;
+    S.in_a = A.in_a + done * (size_t)(ctx->P.n + 1);
+    if (A.in_b) S.in_b = A.in_b + done * (size_t)(ctx->P.n + 1);
+    if (A.gate_codes) S.gate_codes = A.gate_codes + done;
+    S.testvec = A.testvec + done * A.per_ct_stride;
+    if (A.out_trlwe) S.out_trlwe = A.out_trlwe + done * (size_t)(2 * kN);
+    if (A.out_lv1) S.out_lv1 = A.out_lv1 + done * (size_t)(kN + 1);
+    if (A.out_ext2) S.out_ext2 = A.out_ext2 + done * (size_t)(ctx->P.n + 1);
+    S.count = m;
+    return S;
+  };
+  auto launch_pair = [&](const BlindRotateArgs &S) -> int {
     CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(br_pair_kernel(ctx), dim3((unsigned)((count + 1) / 2)), dim3(64u * kPairWaves),
-                       blind_rotate_pair_lds_bytes(ctx->P.n), s, A);
+    hipLaunchKernelGGL(br_pair_kernel(ctx), dim3((unsigned)((S.count + 1) / 2)), dim3(64u * kPairWaves),
+                       blind_rotate_pair_lds_bytes(ctx->P.n), s, S);
     HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_br));
+    return record_end(ctx, s, ctx->ev_br);
+  };
+  auto launch_wide = [&](const BlindRotateArgs &S) -> int {
+    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l) : blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
+    const unsigned wthreads = ctx->br_wide2 ? 64u * kWide2Waves : 128u * (unsigned)ctx->P.l;
+    CHK(record_begin(ctx, s, ctx->ev_br));
+    hipLaunchKernelGGL(br_wide_kernel(ctx), dim3((unsigned)S.count), dim3(wthreads), wlds, s, S);
+    HIPCHK(ctx, hipGetLastError());
+    return record_end(ctx, s, ctx->ev_br);
+  };
+  const bool pairs_on = ctx->br_wide && ctx->br_wide2 && ctx->pair_max > ctx->pair_lo;
+  if (pairs_on && count > ctx->pair_lo && count <= ctx->pair_max) {
+    CHK(launch_pair(A));
+    ctx->bootstraps += count;
+    return TFHE_HIP_OK;
+  }
+  // 2N < count <= 3N: the first 2N as pairs, the rest one per workgroup (3.6 + 2.2 ms; three rounds of singles: 6.4)
+  if (pairs_on && ctx->pair_max == 2 * ctx->pair_lo && count > ctx->pair_max && count <= ctx->pair_max + ctx->pair_lo &&
+      count <= ctx->wide_max) {
+    CHK(launch_pair(part(0, ctx->pair_max)));
+    CHK(launch_wide(part(ctx->pair_max, count - ctx->pair_max)));
     ctx->bootstraps += count;
     return TFHE_HIP_OK;
   }
   if (ctx->br_wide && count <= ctx->wide_max) {
-    br_kernel_t kern = br_wide_kernel(ctx);
-    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l) : blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
-    const unsigned wthreads = ctx->br_wide2 ? 64u * kWide2Waves : 128u * (unsigned)ctx->P.l;
-    CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(kern, dim3((unsigned)count), dim3(wthreads), wlds, s, A);
-    HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_br));
+    CHK(launch_wide(A));
     ctx->bootstraps += count;
     return TFHE_HIP_OK;
   }
@@ -335,15 +362,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (chunk == 0 || chunk > count) chunk = count;
   for (size_t done = 0; done < count; done += chunk) {
     const size_t m = (count - done < chunk) ? count - done : chunk;
-    BlindRotateArgs S = A;
-    S.in_a = A.in_a + done * (size_t)(ctx->P.n + 1);
-    if (A.in_b) S.in_b = A.in_b + done * (size_t)(ctx->P.n + 1);
-    if (A.gate_codes) S.gate_codes = A.gate_codes + done;
-    S.testvec = A.testvec + done * A.per_ct_stride;
-    if (A.out_trlwe) S.out_trlwe = A.out_trlwe + done * (size_t)(2 * kN);
-    if (A.out_lv1) S.out_lv1 = A.out_lv1 + done * (size_t)(kN + 1);
-    if (A.out_ext2) S.out_ext2 = A.out_ext2 + done * (size_t)(ctx->P.n + 1);
-    S.count = m;
+    const BlindRotateArgs S = part(done, m);
     dim3 grid((unsigned)((m + kBrWaves - 1) / kBrWaves));
     CHK(record_begin(ctx, s, ctx->ev_br));
     hipLaunchKernelGGL(br_kernel(ctx), grid, block, lds, s, S);
