@@ -22,7 +22,7 @@ def main():
     from oracle import oracle as O
     import test_gpu_parity as T
 
-    counts = [1, 2, 3, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 767, 768, 769, 1023, 1024, 1025, 1500, 2047, 2049]
+    counts = [1, 2, 3, 127, 128, 129, 255, 256, 257, 300, 511, 512, 513, 640, 767, 768, 769, 1023, 1024, 1025, 1100, 1500, 2047, 2049, 2200]
     rng = np.random.default_rng(args.seed)
     total = bad = 0
     t0 = time.time()

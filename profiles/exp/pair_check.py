@@ -31,7 +31,7 @@ def child(mode):
             print(f"B={B:4d} digest {h} nand_ok={bool(np.array_equal(sk.decrypt_bool(outs[0]), np.ones(B, bool)))}", flush=True)
         return
     dev = torch.device("cuda", 0)
-    for B in (256, 257, 512, 768, 1024, 1536, 2048, 3072, 4096):
+    for B in (256, 257, 512, 768, 1024, 1100, 1280, 1500, 1536, 2048, 2200, 2500, 3072, 3300, 4096, 4200):
         bits = np.random.default_rng(B).integers(0, 2, B).astype(bool)
         c = torch.from_numpy(sk.encrypt_bool(bits, seed=3).view(np.int32)).to(dev)
         o = torch.empty_like(c)

@@ -344,6 +344,28 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     ctx->bootstraps += count;
     return TFHE_HIP_OK;
   }
+  // The batch kernel's time is a staircase with a step every 4N (one more four-wave workgroup
+  // per CU: 6.9 / 11.5 / 17.1 / 21.8 ms at 1,024 / 2,048 / 3,072 / 4,096).  A tail of up to 2N ciphertexts above a
+  // step is cheaper as a latency-kernel launch of its own (2.2 ms up to N, 3.6 up to 2N) than as a whole further step
+  // (1,100: 9.1 vs 10.8 ms, 2,200: 14.4 vs 17.9, 3,300: 19.7 vs 22.9 -- r3x_pair_kernel.log); done up to 32N, beyond
+  // which the step is a few per cent of the launch.
+  size_t tail = 0;
+  if (pairs_on && ctx->br_chunk == 0 && count > ctx->wide_max && count <= 32 * ctx->pair_lo) {
+    const size_t r = count % (4 * ctx->pair_lo);
+    if (r > 0 && r <= ctx->pair_max && count > r) tail = r;
+  }
+  if (tail) {
+    const size_t head = count - tail;
+    const BlindRotateArgs H = part(0, head);
+    CHK(record_begin(ctx, s, ctx->ev_br));
+    hipLaunchKernelGGL(br_kernel(ctx), dim3((unsigned)((head + kBrWaves - 1) / kBrWaves)), dim3(64 * kBrWaves), br_lds_bytes(ctx), s, H);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(record_end(ctx, s, ctx->ev_br));
+    if (tail <= ctx->pair_lo) CHK(launch_wide(part(head, tail)));
+    else CHK(launch_pair(part(head, tail)));
+    ctx->bootstraps += count;
+    return TFHE_HIP_OK;
+  }
   dim3 block(64 * kBrWaves);
   size_t lds = br_lds_bytes(ctx);
   // Default: ONE launch of the whole batch.  The four waves of a workgroup meet at a barrier every CMUX step

@@ -937,22 +937,25 @@ def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
     assert np.array_equal(outs["wide2"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
 
 
-def test_pair_kernel_is_the_default_between_one_and_two_per_cu(O, keys128):
-    """#CUs < count <= 2 #CUs (257 ... 512 on an MI355X) takes k_blind_rotate_pair by default: an odd count in that
-    range against the CPU path."""
+def test_pair_kernel_and_tail_launches_in_the_default_dispatch(O, keys128):
+    """Default dispatch on an MI355X (N = 256 CUs): N < count <= 2N takes k_blind_rotate_pair (301, odd); 2N < count
+    <= 3N the first 2N as pairs and the rest one per workgroup (700); a tail of up to 2N above a multiple of 4N runs
+    as a latency-kernel launch beside the batch kernel's (1,100 = 1,024 + 76; 1,400 = 1,024 + 376 as pairs).  All
+    against the CPU path."""
     import rs_tfhe_amd as R
 
     sk, ck = keys128
     pk = _cloud_key(ck)
     eng = R.bootstrap.engine_for(pk.params, 0)
     eng.ensure_key(pk)
-    count = 301
     rng = np.random.default_rng(461)
-    A, B = rng.integers(0, 2, count).astype(bool), rng.integers(0, 2, count).astype(bool)
-    ca, cb = sk.encrypt_bool(A, 4610), sk.encrypt_bool(B, 4611)
-    got = eng.batch_gate(O.GATE_NOR, ca, cb)
-    assert np.array_equal(got, O.batch_gate(ck, O.GATE_NOR, ca, cb))
-    assert np.array_equal(sk.decrypt_bool(got), ~(A | B))
+    for count, op in ((301, O.GATE_NOR), (700, O.GATE_XOR), (1100, O.GATE_NAND), (1400, O.GATE_ORYN)):
+        A, B = rng.integers(0, 2, count).astype(bool), rng.integers(0, 2, count).astype(bool)
+        ca, cb = sk.encrypt_bool(A, 4610 + count), sk.encrypt_bool(B, 4611 + count)
+        got = eng.batch_gate(op, ca, cb)
+        assert np.array_equal(got, O.batch_gate(ck, op, ca, cb)), count
+        want = np.array([O.GATE_TRUTH[op](bool(a), bool(b)) for a, b in zip(A, B)])
+        assert np.array_equal(sk.decrypt_bool(got), want), count
 
 
 @pytest.mark.gpu
