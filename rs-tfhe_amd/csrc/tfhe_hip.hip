@@ -332,8 +332,10 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     return TFHE_HIP_OK;
   }
   // 2N < count <= 3N: the first 2N as pairs, the rest one per workgroup (3.6 + 2.2 ms; three rounds of singles: 6.4)
-  if (pairs_on && ctx->pair_max == 2 * ctx->pair_lo && count > ctx->pair_max && count <= ctx->pair_max + ctx->pair_lo &&
-      count <= ctx->wide_max) {
+  // (not at l = 1, where the batch kernel's first step is cheaper than a pair launch plus a single one: SECURITY_UINT4
+  // 4.3 vs 4.9 ms; l = 2: 5.1 vs 5.4, l = 3: 5.8 vs 6.9)
+  if (pairs_on && ctx->P.l >= 2 && ctx->pair_max == 2 * ctx->pair_lo && count > ctx->pair_max &&
+      count <= ctx->pair_max + ctx->pair_lo) {
     CHK(launch_pair(part(0, ctx->pair_max)));
     CHK(launch_wide(part(ctx->pair_max, count - ctx->pair_max)));
     ctx->bootstraps += count;
@@ -352,7 +354,8 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   size_t tail = 0;
   if (pairs_on && ctx->br_chunk == 0 && count > ctx->wide_max && count <= 32 * ctx->pair_lo) {
     const size_t r = count % (4 * ctx->pair_lo);
-    if (r > 0 && r <= ctx->pair_max && count > r) tail = r;
+    // (at l = 1 a pair launch costs as much as the step it would save: tails of up to N only)
+    if (r > 0 && r <= (ctx->P.l == 1 ? ctx->pair_lo : ctx->pair_max) && count > r) tail = r;
   }
   if (tail) {
     const size_t head = count - tail;
@@ -837,7 +840,9 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   // crossover vs the batch kernel (7.0 ms for anything up to 1,024 ciphertexts at 128 bit): the eight-wave form takes
   // 2.2 / 4.5 / 6.6 / 8.5 ms for 1 / 2 / 3 / 4 rounds of one workgroup per CU, the six-wave form 3.0 / 6.1 / 9.1
   // (profiles/exp/logs/r3o_crossover.log, r2q_crossover_latency_vs_batch.log)
-  ctx->wide_max = (ctx->br_wide2 ? 3 : 2) * (size_t)ctx->num_cus;
+  // (three rounds only at l = 3: at l = 1, 2 the batch kernel's first step -- 4.3 / 5.4 ms -- is cheaper than three
+  // rounds of singles -- 6.2 ms)
+  ctx->wide_max = ((ctx->br_wide2 && p->l >= 3) ? 3 : 2) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
   ctx->pair_lo = (size_t)ctx->num_cus;
   ctx->pair_max = 2 * (size_t)ctx->num_cus;
