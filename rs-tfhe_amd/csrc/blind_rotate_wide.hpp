@@ -3,7 +3,7 @@
 // k_blind_rotate_wide (blind_rotate.hpp) gives decomposition row r to wave r: digits, forward FFT, both products
 // with its key row, 16 KiB of partial products through LDS, then waves 0 / 1 sum the 2l partials and run the inverse
 // transforms.  Measured (profiles/exp/latency_ablation.py): 10,300 cycles per CMUX step, of which
-// 2,220 are that exchange (the CU's one LDS store path) and 1,950 the rotated reads + digit extraction that the l
+// 2,220 are that exchange (the CU's two 39-B/cycle LDS store paths) and 1,950 the rotated reads + digit extraction that the l
 // waves of a half all repeat.  This form removes both repetitions:
 //   P0  the digit preparation is SHARED: four waves per half (its l forward waves + 4 - l of the waves without a row)
 //       each compute w = ((X^k acc - acc) + offset) ^ signmask (trgsw.rs:183-186, 144-171) for a quarter of the
@@ -30,9 +30,10 @@ __host__ __device__ __forceinline__ size_t blind_rotate_wide2_lds_bytes(int n, i
          ~(size_t)15;
 }
 
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would
-// make every wave wait at each phase boundary for the key slots it has just prefetched for the NEXT step (measured:
-// 1,150 of 8,170 cycles per step, profiles/exp/logs/r3m_latency_wide2_phases.log).
+// Workgroup barrier that waits for this wave's LDS traffic only: the key slots prefetched for the NEXT step stay in
+// flight across the phase boundaries whatever the compiler would put in front of __syncthreads().  (What cost 1,150 of
+// 8,170 cycles per step was not a vmcnt drain -- this barrier alone changed nothing -- but WHERE the prefetch was issued:
+// see the loop, and profiles/exp/logs/r3m_latency_wide2_phases.log.)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int L, bool FAST>
