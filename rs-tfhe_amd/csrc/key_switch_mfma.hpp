@@ -169,9 +169,10 @@ struct KmPos {
   int blk, u;
 };
 
-// A workgroup = kKmWaves waves x kKmFrags x 32 rows, one column block, one byte plane.  lv1 must be readable for
-// count rounded up to kKmRows rows (rows past count are computed and dropped).  out must be zero on entry: the four
-// byte planes (blockIdx.z) are merged with integer atomics (u32 addition commutes: same bits in any arrival order).
+// A workgroup = kKmWaves waves x kKmFrags x 32 rows, one column block, one byte plane, one chunk of the walk over K.
+// lv1 must be readable for count rounded up to kKmRows rows (rows past count are computed and dropped).  out must be
+// zero on entry: the four byte planes and the `ksplit` K chunks (both decoded from the linear workgroup index below)
+// are merged with integer atomics (u32 addition commutes: same bits in any arrival order).
 // NT = tiles of the widest column block; a block with NT-1 tiles skips the last tile (wave-uniform branch).
 #ifndef TFHE_KM_XCD
 #define TFHE_KM_XCD 1
