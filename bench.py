@@ -59,8 +59,75 @@ def parse():
                     "caller of the pool gets, PCIe included); prints its own JSON line")
     ap.add_argument("--pinned", action="store_true", help="with --pool-devices: operands in pinned host memory "
                     "(tfhe_hip_host_alloc): read and written in place over PCIe, no staging copies")
+    ap.add_argument("--resident", action="store_true", help="with --pool-devices: the batch is RESIDENT on the first device's "
+                    "GPU and goes through tfhe_hip_pool_batch_*_dev (shards scattered / gathered between the members by grouped "
+                    "RCCL send / receive, or peer copies when a device repeats); prints scatter_ms / gather_ms")
+    ap.add_argument("--stage", default=None, choices=["blind_rotate", "ifft", "fft", "poly_mul"],
+                    help="time one stage entry point instead of the gate path: the reference's criterion groups "
+                    "`bootstrapping` (= trgsw::blind_rotate) and `fft_operations` (benches/gate_benchmarks.rs:77-125)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU sample (whole thread sweep)")
     return ap.parse_args()
+
+
+def stage_mode(args):
+    """benches/gate_benchmarks.rs:77-125: `bootstrapping` (one trgsw::blind_rotate) and the `fft_operations` group
+    (fft_forward_1024 = FFTProcessor::ifft, fft_inverse_1024 = ::fft, poly_mul_1024), each as ONE call (criterion's
+    shape) and as a batch.  blind_rotate runs device-resident; the FFT stage entry points take host buffers, so their
+    figures include PCIe both ways (they exist for parity tests: the hot path never leaves the fused kernels)."""
+    import numpy as np
+    import torch
+
+    import rs_tfhe_amd as R
+
+    P = R.params.PARAM_SETS[args.params]
+    eng = R.Engine(P, 0)
+    rng = np.random.default_rng(7)
+    N = R.params.N
+    res = {"metric": f"stage `{args.stage}` ({args.params})", "stage": args.stage, "steps": args.steps, "warmup": args.warmup}
+
+    def timed(fn, reps):
+        for _ in range(max(1, args.warmup)):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    if args.stage == "blind_rotate":
+        sk = R.SecretKey.new(P, seed=2024)
+        eng.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+        B = args.batch
+        cts = sk.encrypt_bool(rng.integers(0, 2, B).astype(bool), seed=5)
+        tin = torch.from_numpy(cts.view(np.int32)).to("cuda:0")
+        tout = torch.empty((B, 2, N), dtype=torch.int32, device="cuda:0")
+        one = timed(lambda: eng.batch_blind_rotate_dev(tin[:1], tout[:1]), max(5, args.steps))
+        eng.set_profiling(True)
+        whole = timed(lambda: eng.batch_blind_rotate_dev(tin, tout), args.steps)
+        kt = eng.kernel_times()
+        res.update({"reference_bench": "bootstrapping (trgsw::blind_rotate), benches/gate_benchmarks.rs:77-90",
+                    "single_call_ms": round(one * 1e3, 3), "batch": B, "batch_ms": round(whole * 1e3, 2),
+                    "value": round(B / whole, 1), "unit": "blind rotations/s",
+                    "kernel_ms_per_launch": round(kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"]), 3),
+                    "dispatch": eng.describe_dispatch(B), "device_resident": True})
+    else:
+        B = min(args.batch, 16384)
+        polys = rng.integers(0, 2**32, (B, N), dtype=np.uint64).astype(np.uint32)
+        if args.stage == "ifft":
+            fn1, fnB, name = (lambda: eng.batch_ifft(polys[:1])), (lambda: eng.batch_ifft(polys)), "fft_forward_1024 (FFTProcessor::ifft)"
+        elif args.stage == "fft":
+            spec = eng.batch_ifft(polys)
+            fn1, fnB, name = (lambda: eng.batch_fft(spec[:1])), (lambda: eng.batch_fft(spec)), "fft_inverse_1024 (FFTProcessor::fft)"
+        else:
+            fn1, fnB, name = (lambda: eng.batch_poly_mul(polys[:1], polys[:1])), (lambda: eng.batch_poly_mul(polys, polys)), "poly_mul_1024"
+        one = timed(fn1, max(20, args.steps))
+        whole = timed(fnB, args.steps)
+        res.update({"reference_bench": f"fft_operations/{name}, benches/gate_benchmarks.rs:92-125",
+                    "single_call_ms": round(one * 1e3, 4), "batch": B, "batch_ms": round(whole * 1e3, 2),
+                    "value": round(B / whole, 1), "unit": "polynomials/s", "pcie_inclusive": True})
+    eng.close()
+    print(json.dumps(res), flush=True)
 
 
 def pool_mode(args):
@@ -71,13 +138,15 @@ def pool_mode(args):
 
     devices = [int(d) for d in args.pool_devices.split(",")]
     P = R.params.PARAM_SETS[args.params]
-    gate = R.engine.GATE_IDS[args.gate]
     sk = R.SecretKey.new(P, seed=2024)
     pool = R.Pool(P, devices)
     t0 = time.perf_counter()
     pool.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
     keygen_s = time.perf_counter() - t0
     B = args.batch * len(devices)
+    if args.resident:
+        return pool_resident_mode(args, R, pool, sk, devices, B, keygen_s)
+    gate = R.engine.GATE_IDS[args.gate]
     rng = np.random.default_rng(1000)
     bits_a, bits_b = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
     ca, cb = sk.encrypt_bool(bits_a, seed=11), sk.encrypt_bool(bits_b, seed=12)
@@ -99,14 +168,77 @@ def pool_mode(args):
         "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
 
 
-def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch):
+def pool_resident_mode(args, R, pool, sk, devices, B, keygen_s):
+    """The whole batch lives on the first device's GPU; tfhe_hip_pool_batch_*_dev cuts it over the members (shard r on
+    member r), moves the shards device to device and brings the results back in input order.  `--gate mixed` is
+    BASELINE configs[4]'s circuit level (half Gates::mux in the reference's formula, half hom_xor: two blind-rotation
+    launches + one key switch) through the ONE pool handle."""
+    import numpy as np
+    import torch
+
+    P = pool.params
+    dev = torch.device("cuda", devices[0])
+    rng = np.random.default_rng(1000)
+    bits = [rng.integers(0, 2, B).astype(bool) for _ in range(3)]
+    ta, tb, tc = (torch.from_numpy(sk.encrypt_bool(b, seed=11 + i).view(np.int32)).to(dev) for i, b in enumerate(bits))
+    to = torch.empty_like(ta)
+    h = B // 2
+    codes = torch.full((B - h,), R.engine.XOR, dtype=torch.uint8, device=dev)
+    gate = None if args.gate == "mixed" else R.engine.GATE_IDS[args.gate]
+
+    def step():
+        if args.gate == "mixed":
+            mo, xo = R.circuit.mux_and_gates_dev(pool, ta[:h], tb[:h], tc[:h], codes, ta[h:], tb[h:])
+            to[:h].copy_(mo)
+            to[h:].copy_(xo)
+        else:
+            pool.batch_gate_dev(gate, ta, tb, to)
+
+    def fence():
+        pool.synchronize()
+        torch.cuda.synchronize()
+
+    with torch.cuda.device(dev):
+        for _ in range(args.warmup):
+            step()
+        fence()
+        pool.set_profiling(True)
+        pool.transfer_times()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        tt = pool.transfer_times()
+        pool.set_profiling(False)
+    out = to.cpu().numpy().view(np.uint32)
+    if args.gate == "mixed":
+        ok = bool(np.array_equal(sk.decrypt_bool(out[h:]), bits[0][h:] ^ bits[1][h:]))
+        boots = 2 * B
+    else:
+        ok = bool(np.array_equal(sk.decrypt_bool(out), GATE_TRUTH[args.gate](bits[0], bits[1])))
+        boots = B
+    calls = max(1, tt["calls"])
+    print(json.dumps({
+        "metric": f"gate-bootstraps/sec ({args.gate}, {args.params}), single process, tfhe_hip_pool_*_dev over a batch resident on device {devices[0]}",
+        "value": round(boots * args.steps / elapsed, 1), "unit": "bootstraps/s", "devices": devices, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "batch_total": B,
+        "resident_on": devices[0], "transport": pool.data_transport, "key_transport": pool.key_transport,
+        # per pool call: the longest single shard transfer (transfers to different members overlap) and the sum over members
+        "scatter_ms": round(tt["scatter_ms_max"], 3), "gather_ms": round(tt["gather_ms_max"], 3),
+        "scatter_ms_sum_per_call": round(tt["scatter_ms_sum"] / calls, 3), "gather_ms_sum_per_call": round(tt["gather_ms_sum"] / calls, 3),
+        "scatter_MB_per_call": round(tt["scatter_bytes"] / calls / 1e6, 1), "gather_MB_per_call": round(tt["gather_bytes"] / calls / 1e6, 1),
+        "pool_calls": tt["calls"], "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
+
+
+def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
     """Roofline of the second kernel.  Base-4 sets at batch sizes the matrix-core kernel takes: int8 MFMA ops of the
     one-hot contraction (2 x ciphertexts x 4*N*t rows x padded output columns x 4 byte planes) against the guide's
     measured i8 ceiling (3,944 TOPS, v_mfma_i32_16x16x64_i8; 32x32x32: 4,404), with the clock the kernel sustained
     (the matrix pipes are current-limited: 1.6-2.4 GHz depending on operand toggling,
     profiles/exp/logs/r3d_ubench_mfma.log).  Other sets: the LDS-ring kernels, instruction-issue bound."""
-    mfma = P.basebit == 2 and batch >= 64 and os.environ.get("TFHE_HIP_KS_MFMA", "1") != "0"
-    out = {"avg_launch_ms": round(ks_ms, 3)}
+    mfma = "key_switch=mfma" in plan  # what the library says it launched (tfhe_hip_describe_dispatch)
+    out = {"avg_launch_ms": round(ks_ms, 3), "kernel": "k_key_switch_" + plan.split("key_switch=")[-1].split("(")[0] if plan else None}
     if mfma and ks_ms > 0:
         cols = -(-(P.n + 1) // 32) * 32
         ops = 2.0 * per_launch * (4 * 1024 * P.iks_t) * cols * 4
@@ -130,6 +262,8 @@ def main():
     args = parse()
     if args.pool_devices:
         return pool_mode(args)
+    if args.stage:
+        return stage_mode(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start it as a child (never exec after touching the GPU)
@@ -347,6 +481,12 @@ def main():
         print("bench.py: " + isa_source, file=sys.stderr)
     wave_steps_per_s = P.n * per_launch / (br_ms * 1e-3) if br_ms > 0 else 0.0  # CMUX steps of one wave, whole chip
     tflops = wave_steps_per_s * 64 * isa["f64_flop_per_lane"] / 1e12
+    # SURVEY 8(d)'s ALGORITHMIC flops per CMUX step (the contract figure): (2l+2) transforms of 26,112 flops + 2l digit
+    # rows x 2 spectra x 512 complex MACs of 8 flops = 258,048 at l = 3, 120,832 at l = 1.  `frac` prices the flops the
+    # kernel EXECUTES (from its ISA: a few per cent more -- twiddle folding, the rounding); both are printed.
+    alg_flop_per_step = (2 * P.l + 2) * 26112 + 2 * P.l * 8192
+    tflops_alg = wave_steps_per_s * alg_flop_per_step / 1e12
+    plan = eng.describe_dispatch(int(per_launch)) if per_launch else ""
     shader_mhz = clk["shader_mhz"] or None
     # issue slots: 1,024 SIMDs, one FP64 wave-instruction per 4 cycles (16 lanes/clk), at the clock the kernel ran at
     have_isa = isa["valu"] is not None
@@ -359,6 +499,10 @@ def main():
         "peak": 78.6,
         "unit": "TFLOP/s",
         "frac": round(tflops / 78.6, 4),
+        "achieved_algorithmic": round(tflops_alg, 2),
+        "frac_algorithmic": round(tflops_alg / 78.6, 4),
+        "algorithmic_flop_per_cmux_step": alg_flop_per_step,
+        "dispatch": plan,
         "traffic": traffic,
         "traffic_source": traffic_source,
         "avg_launch_ms": round(br_ms, 3),
@@ -391,7 +535,7 @@ def main():
         "algorithmic_hbm_ratio_to_peak": round(achieved / 8000.0, 4),
         "whole_path_algorithmic_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
         "key_switch_avg_launch_ms": round(ks_ms, 3),
-        "key_switch": key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, B),
+        "key_switch": key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, B, plan),
     }
 
     cpu = None

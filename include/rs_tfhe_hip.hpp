@@ -770,6 +770,19 @@ class DevicePool {
     check(tfhe_hip_pool_batch_gate(pool_, gate, fa, fb, out, inputs.size()));
     return detail::unflatten(out, inputs.size(), n);
   }
+  // The same map for a batch that is already RESIDENT on member `home`'s GPU (device pointers, [count][n+1]): the
+  // shards travel by grouped RCCL send / receive (or peer copies), results come back to `out` in input order.  Only
+  // enqueues, on `stream` (a hipStream_t of the home GPU; nullptr = the member's own); synchronize() drains the members.
+  void batch_gate_dev(int home, int gate, const Torus *a, const Torus *b, Torus *out, size_t count, void *stream = nullptr) {
+    check(tfhe_hip_pool_batch_gate_dev(pool_, home, gate, a, b, out, count, stream));
+  }
+  void batch_gates_mixed_dev(int home, const uint8_t *gates, const Torus *a, const Torus *b, Torus *out, size_t count,
+                             bool keyswitch = true, void *stream = nullptr) {
+    check(keyswitch ? tfhe_hip_pool_batch_gates_mixed_dev(pool_, home, gates, a, b, out, count, stream)
+                    : tfhe_hip_pool_batch_gates_mixed_nks_dev(pool_, home, gates, a, b, out, count, stream));
+  }
+  void synchronize() { check(tfhe_hip_pool_synchronize(pool_)); }
+  const char *data_transport() const { return tfhe_hip_pool_data_transport(pool_); }
   tfhe_hip_pool *handle() const { return pool_; }
 
  private:

@@ -95,8 +95,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *params, int device, tfhe_hip_ctx 
 /* Replaces: Drop for SpqliosFFT (spqlios_fft.rs:84-90). NULL is a no-op. */
 void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx);
 
-/* Text of the last error on this context (or of the last failed create when
- * ctx == NULL).  Never NULL. */
+/* Text of the CALLING THREAD's last error on this context (or of its last failed create when ctx == NULL).
+ * Never NULL.  The text is kept per (thread, handle): threads that share a context (`Send + Sync`,
+ * src/bootstrap/mod.rs:23) each read their own failure, and the pointer stays valid until the same thread's next
+ * failing call on the same handle.  tfhe_hip_pool_last_error follows the same rule. */
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx);
 
 /* ---- key views: several resident cloud keys on ONE context -----------------------------------------
@@ -335,6 +337,29 @@ int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
  * sample): the clock that prices it against the int8 MFMA roofline. */
 int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out);
 
+/* Which kernels a batch of `count` ciphertexts runs on under this handle's dispatch rules (the cloud key must be
+ * loaded: the base-4 matrix-core key switch exists only once its byte planes do), as one line of text:
+ *   "blind_rotate=batch[0,1024)+single[1024,1100) key_switch=mfma(k=4)"
+ * blind_rotate: up to two launches over contiguous parts of the batch, each `batch` (k_blind_rotate, one wave per
+ * ciphertext), `single` (k_blind_rotate_wide2, one eight-wave workgroup per ciphertext) or `pair`
+ * (k_blind_rotate_pair); key_switch: `mfma` / `sliced` / `b4` / `generic` / `split` with the number of partial
+ * walks merged by integer atomics (k) and, for `sliced`, the accumulator sets per lane.  Every choice returns the
+ * same result bits (tests/test_gpu_parity.py::test_dispatch_crossovers_bit_exact); the line exists so that tests,
+ * profiles and bench.py can say WHICH kernels a number was measured on.  buf receives a NUL-terminated string.
+ *
+ * Environment variables read at tfhe_hip_ctx_create / tfhe_hip_pool_create -- the complete supported list:
+ *   TFHE_HIP_BR_KERNEL = auto | batch | single | pair            (default auto) run that blind-rotation kernel at
+ *                                                                 every batch size instead of picking per size
+ *   TFHE_HIP_KS_KERNEL = auto | mfma | sliced | b4 | generic | split  (default auto) likewise for the key switch;
+ *                        creation fails with TFHE_HIP_EINVAL when the parameter set cannot run the kernel named
+ *   TFHE_HIP_POOL_RCCL = 0 | 1 | 2    pools: 0 never use RCCL (peer copies only), 1 (default) RCCL when the pool's
+ *                                      devices are distinct, 2 also for a pool of one (plumbing test)
+ *   TFHE_HIP_POOL_PINNED_STAGING = 0 | 1   pools: stage pageable operands through per-member pinned arenas
+ *                                      (default: 1 for pools of several members)
+ * Anything else (crossover counts, chunk counts, ring depths) is compiled in; overrides for those exist only in
+ * experiment builds (-DTFHE_EXPERIMENT, profiles/exp/build_variants.sh) and are not part of this interface. */
+int tfhe_hip_describe_dispatch(tfhe_hip_ctx *ctx, size_t count, char *buf, size_t buflen);
+
 /* Block until everything this context enqueued -- on its own stream and on the caller's stream of the
  * last *_dev call -- has finished.  Returns TFHE_HIP_EINVAL (and clears the condition) if a
  * tfhe_hip_batch_gates_mixed_dev launch since the last call met a gate code outside tfhe_hip_gate. */
@@ -358,7 +383,8 @@ int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int 
 void tfhe_hip_pool_destroy(tfhe_hip_pool *pool);
 int tfhe_hip_pool_size(const tfhe_hip_pool *pool);
 /* How the pool's last cloud key reached the members: "rccl" (one grouped ncclBroadcast per key buffer over xGMI,
- * in place in the engine layouts; librccl is opened at run time; used when the pool's devices are distinct) or
+ * in place in the engine layouts; librccl is opened at run time; used when the pool's devices are distinct; the
+ * communicator is created once per pool, on first use, and lives until tfhe_hip_pool_destroy) or
  * "peer-copy" (serial hipMemcpyPeer from member 0: the fallback, and what pools with a repeated device use).
  * TFHE_HIP_POOL_RCCL=0 disables the RCCL path. */
 const char *tfhe_hip_pool_key_transport(const tfhe_hip_pool *pool);
@@ -388,18 +414,84 @@ int tfhe_hip_pool_gen_cloud_key(tfhe_hip_pool *pool, const uint32_t *key_lv0, co
 int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *pool, int member, double *bsk, uint32_t *ksk,
                                    uint32_t *decomp_offset, uint32_t *testvec);
 
-/* The batched hot path over all members: same arguments and semantics as the single-context host entry
- * points of the same name (gates.rs:352-547; gates.rs:157-199; bootstrap/{vanilla,lut}.rs; trgsw.rs:289-305). */
+/* The batched hot path over all members, HOST pointers: same arguments and semantics as the single-context host
+ * entry points of the same name (gates.rs:352-547; gates.rs:157-199; bootstrap/{vanilla,lut}.rs; trgsw.rs:289-305;
+ * tlwe.rs:129-214).  One host thread per shard; results land in the caller's output slice in input order. */
 int tfhe_hip_pool_batch_gate(tfhe_hip_pool *pool, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
                              size_t count);
 int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *pool, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                     uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_gates_mixed_nks(tfhe_hip_pool *pool, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                        uint32_t *out, size_t count);
 int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *pool, const uint32_t *in, const uint32_t *testvec, int per_ct,
                                   int keyswitch, uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_tlwe_lincomb(tfhe_hip_pool *pool, uint32_t ca, const uint32_t *a, uint32_t cb, const uint32_t *b,
+                                     uint32_t cconst, uint32_t *out, size_t count);
+int tfhe_hip_pool_batch_lincomb_bootstrap(tfhe_hip_pool *pool, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                          const uint32_t *b, uint32_t cconst, const uint32_t *testvec, int per_ct,
+                                          int keyswitch, uint32_t *out, size_t count);
 int tfhe_hip_pool_batch_mux(tfhe_hip_pool *pool, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c,
                             uint32_t *out, size_t count);
 int tfhe_hip_pool_batch_blind_rotate(tfhe_hip_pool *pool, const uint32_t *in, const uint32_t *testvec,
                                      uint32_t *out_trlwe, size_t count);
+
+/* The same calls for a batch that is RESIDENT ON ONE MEMBER'S GPU.
+ * Replaces: the same Rayon par_map (src/parallel/rayon_impl.rs:40-47, src/gates.rs:357-383) for a caller whose
+ * ciphertexts already live in device memory -- the levels of a circuit, the output of a previous pool call -- and
+ * that has no torch.distributed to shard them with: every operand and the result are DEVICE pointers on member
+ * `home_member`'s GPU, and `stream` is a stream of that GPU (NULL = the member context's own).  The call only
+ * ENQUEUES, like the single-context *_dev calls:
+ *   - the batch is cut as tfhe_hip_pool_shard cuts it over tfhe_hip_pool_members_for(count) members; shard r runs on
+ *     member (home_member + r) mod size, so shard 0 -- and any batch too small to cut -- never leaves home;
+ *   - every other shard travels to its member and its result back by ONE grouped ncclSend / ncclRecv pair per
+ *     operand and peer over the pool's persistent RCCL communicator (all xGMI links concurrently; shared operands
+ *     such as one test vector for the batch are sent whole to every peer), or by hipMemcpyPeerAsync behind events
+ *     when the pool has no communicator (a repeated device, no librccl, TFHE_HIP_POOL_RCCL=0) --
+ *     tfhe_hip_pool_data_transport() says which ran;
+ *   - members compute on their own streams, home on `stream`; work enqueued on `stream` after the call sees the
+ *     complete result (the gather is ordered into `stream`).  Results are in input order.
+ * Errors detected while enqueueing are returned; tfhe_hip_pool_synchronize() drains the members' streams and reports
+ * device-side conditions (see tfhe_hip_synchronize).  The members must not be used through tfhe_hip_pool_ctx() by
+ * other threads meanwhile.  gates (mixed forms) is a device pointer too. */
+int tfhe_hip_pool_batch_gate_dev(tfhe_hip_pool *pool, int home_member, int gate, const uint32_t *a, const uint32_t *b,
+                                 uint32_t *out, size_t count, void *stream);
+int tfhe_hip_pool_batch_gates_mixed_dev(tfhe_hip_pool *pool, int home_member, const uint8_t *gates, const uint32_t *a,
+                                        const uint32_t *b, uint32_t *out, size_t count, void *stream);
+int tfhe_hip_pool_batch_gates_mixed_nks_dev(tfhe_hip_pool *pool, int home_member, const uint8_t *gates,
+                                            const uint32_t *a, const uint32_t *b, uint32_t *out, size_t count,
+                                            void *stream);
+int tfhe_hip_pool_batch_bootstrap_dev(tfhe_hip_pool *pool, int home_member, const uint32_t *in, const uint32_t *testvec,
+                                      int per_ct, int keyswitch, uint32_t *out, size_t count, void *stream);
+int tfhe_hip_pool_batch_tlwe_lincomb_dev(tfhe_hip_pool *pool, int home_member, uint32_t ca, const uint32_t *a,
+                                         uint32_t cb, const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count,
+                                         void *stream);
+int tfhe_hip_pool_batch_lincomb_bootstrap_dev(tfhe_hip_pool *pool, int home_member, uint32_t ca, const uint32_t *a,
+                                              uint32_t cb, const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
+                                              int per_ct, int keyswitch, uint32_t *out, size_t count, void *stream);
+int tfhe_hip_pool_batch_mux_dev(tfhe_hip_pool *pool, int home_member, int naive, const uint32_t *a, const uint32_t *b,
+                                const uint32_t *c, uint32_t *out, size_t count, void *stream);
+int tfhe_hip_pool_batch_blind_rotate_dev(tfhe_hip_pool *pool, int home_member, const uint32_t *in,
+                                         const uint32_t *testvec, uint32_t *out_trlwe, size_t count, void *stream);
+
+/* Drain every member's own stream (what the *_dev pool calls enqueued on the members); the caller's `stream` is the
+ * caller's to synchronise.  Reports the device-side conditions tfhe_hip_synchronize reports. */
+int tfhe_hip_pool_synchronize(tfhe_hip_pool *pool);
+/* How the last *_dev pool call moved its shards: "rccl", "peer-copy", or "none" (nothing left the home GPU). */
+const char *tfhe_hip_pool_data_transport(const tfhe_hip_pool *pool);
+
+/* Measurement: tfhe_hip_set_profiling on every member, plus HIP-event pairs around every shard transfer of the *_dev
+ * pool calls.  tfhe_hip_pool_get_transfer_times synchronises those events, returns the sums since the last call and
+ * resets them: *_ms_sum over all transfers, *_ms_max the longest single one (transfers to different peers overlap).
+ * A scatter is timed on the receiving member's stream; a gather on the sending member's stream (peer copies) or on
+ * the home stream (RCCL: one grouped receive, which also waits for the slowest member's result). */
+typedef struct tfhe_hip_pool_transfer_times {
+  double scatter_ms_sum, scatter_ms_max;
+  double gather_ms_sum, gather_ms_max;
+  uint64_t scatter_bytes, gather_bytes;
+  uint64_t calls; /* *_dev pool calls since the last read */
+} tfhe_hip_pool_transfer_times;
+int tfhe_hip_pool_set_profiling(tfhe_hip_pool *pool, int enabled);
+int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *pool, tfhe_hip_pool_transfer_times *out);
 
 #ifdef __cplusplus
 }

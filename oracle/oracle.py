@@ -439,6 +439,25 @@ def identity_key_switching(ck: CloudKey, ct_lv1) -> np.ndarray:
     return out
 
 
+def batch_identity_key_switching(ck: CloudKey, cts_lv1) -> np.ndarray:
+    """identity_key_switching (trgsw.rs:332-360) mapped over [count][N+1]; the C calls run on a few host threads
+    (ctypes releases the GIL) -- the tests' counts reach four figures."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    cts_lv1 = _u32(cts_lv1).reshape(-1, N + 1)
+    out = np.empty((len(cts_lv1), ck.params.n + 1), np.uint32)
+    cp = ck.params.c()
+    ksk = ck.key_switching_key
+    fn = lib().orc_identity_key_switching
+
+    def one(i):
+        fn(_p(cts_lv1[i]), _p(ksk), C.byref(cp), _p(out[i]))
+
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        list(ex.map(one, range(len(cts_lv1))))
+    return out
+
+
 def batch_gate(ck: CloudKey, op: int, a, b, nthreads: int = 0) -> np.ndarray:
     a = _u32(a).reshape(-1, ck.params.n + 1)
     bb = _u32(b).reshape(-1, ck.params.n + 1) if b is not None else None

@@ -45,9 +45,18 @@ class ClockSample(C.Structure):
                 ("rtc_ticks", C.c_uint64)]
 
 
+class PoolTransferTimes(C.Structure):
+    """struct tfhe_hip_pool_transfer_times"""
+
+    _fields_ = [("scatter_ms_sum", C.c_double), ("scatter_ms_max", C.c_double), ("gather_ms_sum", C.c_double),
+                ("gather_ms_max", C.c_double), ("scatter_bytes", C.c_uint64), ("gather_bytes", C.c_uint64),
+                ("calls", C.c_uint64)]
+
+
 _P = C.c_void_p
 _SZ = C.c_size_t
 _CTX = C.c_void_p
+_U32 = C.c_uint32
 
 # name -> (restype, argtypes); every symbol include/tfhe_hip.h declares
 SIGNATURES = {
@@ -98,6 +107,7 @@ SIGNATURES = {
     "tfhe_hip_get_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_get_key_switch_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
+    "tfhe_hip_describe_dispatch": (C.c_int, [_CTX, _SZ, C.c_char_p, _SZ]),
     # several GPUs behind one handle
     "tfhe_hip_pool_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(_CTX)]),
     "tfhe_hip_pool_destroy": (None, [_CTX]),
@@ -117,6 +127,23 @@ SIGNATURES = {
     "tfhe_hip_pool_batch_bootstrap": (C.c_int, [_CTX, _P, _P, C.c_int, C.c_int, _P, _SZ]),
     "tfhe_hip_pool_batch_mux": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ]),
     "tfhe_hip_pool_batch_blind_rotate": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
+    "tfhe_hip_pool_batch_gates_mixed_nks": (C.c_int, [_CTX, _P, _P, _P, _P, _SZ]),
+    "tfhe_hip_pool_batch_tlwe_lincomb": (C.c_int, [_CTX, _U32, _P, _U32, _P, _U32, _P, _SZ]),
+    "tfhe_hip_pool_batch_lincomb_bootstrap": (C.c_int, [_CTX, _U32, _P, _U32, _P, _U32, _P, C.c_int, C.c_int, _P, _SZ]),
+    # ... for a batch resident on one member's GPU (home_member, device pointers, stream)
+    "tfhe_hip_pool_batch_gate_dev": (C.c_int, [_CTX, C.c_int, C.c_int, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_gates_mixed_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_gates_mixed_nks_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_bootstrap_dev": (C.c_int, [_CTX, C.c_int, _P, _P, C.c_int, C.c_int, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_tlwe_lincomb_dev": (C.c_int, [_CTX, C.c_int, _U32, _P, _U32, _P, _U32, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_lincomb_bootstrap_dev": (
+        C.c_int, [_CTX, C.c_int, _U32, _P, _U32, _P, _U32, _P, C.c_int, C.c_int, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_mux_dev": (C.c_int, [_CTX, C.c_int, C.c_int, _P, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_pool_batch_blind_rotate_dev": (C.c_int, [_CTX, C.c_int, _P, _P, _P, _SZ, _P]),
+    "tfhe_hip_pool_synchronize": (C.c_int, [_CTX]),
+    "tfhe_hip_pool_data_transport": (C.c_char_p, [_CTX]),
+    "tfhe_hip_pool_set_profiling": (C.c_int, [_CTX, C.c_int]),
+    "tfhe_hip_pool_get_transfer_times": (C.c_int, [_CTX, C.POINTER(PoolTransferTimes)]),
 }
 
 _lib = None

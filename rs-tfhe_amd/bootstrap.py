@@ -36,11 +36,30 @@ def engine_for(params: SecurityParams, device: int = 0) -> Engine:
         return eng
 
 
+def _evict_idle(views: dict, room_for: int = 1) -> None:
+    """(_engines_mu held) Drop least recently used IDLE views until `room_for` more fit under MAX_RESIDENT_KEYS:
+    each resident key pins 172 MB + 104 MB of byte planes on the device at SECURITY_128_BIT and, through the view's
+    reference to its CloudKey, ~160 MB of host memory."""
+    idle = [k for k, v in views.items() if v._users == 0]
+    while len(views) + room_for > MAX_RESIDENT_KEYS and idle:
+        victim = min(idle, key=lambda k: views[k]._last_use)
+        idle.remove(victim)
+        views.pop(victim).close()
+
+
 def adopt_view(cloud_key, view: Engine) -> None:
-    """Register a key view that already holds `cloud_key` (e.g. the one it was generated in): first use uploads nothing."""
+    """Register a key view that already holds `cloud_key` (e.g. the one it was generated in): first use uploads nothing.
+    Counts against MAX_RESIDENT_KEYS like any other view: a loop of SecretKey.cloud_key() calls (key rotation, test
+    suites) keeps at most that many keys resident instead of growing without bound."""
     with _engines_mu:
+        views = _views.setdefault((view.params, view.device), {})
+        stale = views.pop(id(cloud_key), None)
+        if stale is not None and stale is not view and stale._users == 0:
+            stale.close()
+        _evict_idle(views)
         view._key = cloud_key
-        _views.setdefault((view.params, view.device), {})[id(cloud_key)] = view
+        view._last_use = next(_ticks)
+        views[id(cloud_key)] = view
 
 
 @contextlib.contextmanager
@@ -61,11 +80,7 @@ def keyed_engine(cloud_key, device: int = 0):
             view = None
         fresh = view is None
         if fresh:
-            idle = [k for k, v in views.items() if v._users == 0]
-            while len(views) >= MAX_RESIDENT_KEYS and idle:
-                victim = min(idle, key=lambda k: views[k]._last_use)
-                idle.remove(victim)
-                views.pop(victim).close()
+            _evict_idle(views)
             view = base.new_key_view()
             view._key = cloud_key  # held: the id cannot be recycled while the view lives
             views[id(cloud_key)] = view

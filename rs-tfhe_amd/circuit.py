@@ -94,9 +94,12 @@ class Circuit:
         return out
 
     # -- execution -----------------------------------------------------------------------
-    def run_dev(self, eng: E.Engine, inputs, stream=None):
+    def run_dev(self, eng, inputs, stream=None):
         """inputs: int32 CUDA tensor [n_inputs][B][n+1]; returns the wire store [n_wires][B][n+1]
-        (int32 CUDA tensor, rows of non-existent wires undefined).  One launch per level."""
+        (int32 CUDA tensor, rows of non-existent wires undefined).  One launch per level.
+        `eng`: an Engine, or a Pool -- then the wires live on the pool's home member (`pool.home`) and every level is
+        one `tfhe_hip_pool_batch_gates_mixed_dev` call: its gates x batch are cut over the members, the shards travel
+        by grouped RCCL send / receive and the level's results are back on the home GPU, in order, for the next gather."""
         import torch
 
         n_in, B, w = inputs.shape
@@ -133,14 +136,16 @@ class Circuit:
             self._plans[key] = plan
         return plan
 
-    def run(self, eng: E.Engine, inputs) -> np.ndarray:
-        """Host convenience: inputs uint32 [n_inputs][B][n+1] -> all wires uint32 [n_wires][B][n+1]."""
+    def run(self, eng, inputs) -> np.ndarray:
+        """Host convenience: inputs uint32 [n_inputs][B][n+1] -> all wires uint32 [n_wires][B][n+1].  `eng`: Engine or Pool."""
         import torch
 
         dev = torch.device("cuda", eng.device)
         t = torch.from_numpy(np.ascontiguousarray(inputs, dtype=np.uint32).view(np.int32)).to(dev)
         with torch.cuda.device(dev):
             wires = self.run_dev(eng, t)
+            if isinstance(eng, E.Pool):
+                eng.synchronize()
             torch.cuda.synchronize()
         return wires.cpu().numpy().view(np.uint32)
 
@@ -165,7 +170,7 @@ def _on_stream(stream):
 
 
 # ---- LUT arithmetic: the nibble adder of examples/lut_add_two_numbers.rs, batched ---------------
-def lut_add_u8_dev(eng: E.Engine, a_low, a_high, b_low, b_high, stream=None):
+def lut_add_u8_dev(eng, a_low, a_high, b_low, b_high, stream=None):
     """8-bit addition with three programmable bootstraps per byte pair instead of eight gate
     bootstraps per bit pair (examples/lut_add_two_numbers.rs:82-158), for a whole batch, on the device.
 
@@ -196,13 +201,15 @@ def lut_add_u8_dev(eng: E.Engine, a_low, a_high, b_low, b_high, stream=None):
     return sum_low, sum_high, carry
 
 
-def mux_and_gates_dev(eng: E.Engine, a, b, c, codes, xa, xb, stream=None):
+def mux_and_gates_dev(eng, a, b, c, codes, xa, xb, stream=None):
     """One circuit level holding `M` Gates::mux (the reference's formula, src/gates.rs:157-183) beside `X` two-input
     gates (`codes`: uint8 device tensor [X]) -- BASELINE configs[4] is M hom_mux + X hom_xor -- in TWO blind-rotation
     launches and ONE key switch whatever M and X:
       launch 1  [and(a, b) | and(not(a), c)] for all M, bootstrap_without_key_switch      (gates.rs:165-177)
       launch 2  [or(u1, u2) for all M | the X other gates], full bootstrap                   (gates.rs:179-182)
-    a, b, c: int32 CUDA tensors [M][n+1]; xa, xb: [X][n+1].  Returns (mux_out [M][n+1], gate_out [X][n+1])."""
+    a, b, c: int32 CUDA tensors [M][n+1]; xa, xb: [X][n+1].  Returns (mux_out [M][n+1], gate_out [X][n+1]).
+    `eng`: an Engine, or a Pool (tensors on its home member's GPU): each of the two launches is then a pool call cut
+    over the members -- configs[4]'s level through ONE handle."""
     import torch
 
     M, X = a.shape[0], xa.shape[0]
@@ -218,7 +225,7 @@ def mux_and_gates_dev(eng: E.Engine, a, b, c, codes, xa, xb, stream=None):
     return out[:M], out[M:]
 
 
-def lut_add_u8(eng: E.Engine, a_low, a_high, b_low, b_high):
+def lut_add_u8(eng, a_low, a_high, b_low, b_high):
     """Host-array form of lut_add_u8_dev: numpy [count][n+1] in, (sum_low, sum_high, carry) out."""
     from .lut import Generator
 

@@ -14,11 +14,34 @@
 #include <system_error>
 #include <thread>
 
+struct RcclApi;
 struct tfhe_hip_pool {
   std::vector<tfhe_hip_ctx *> ctxs;
-  std::mutex mu;  // one batch at a time per pool (the contexts' host staging buffers are per context)
-  std::string err = "";
+  tfhe_hip_pool *parent = nullptr;  // non-null: a key view of `parent` (same devices, streams, staging, communicator and mutex)
+  int views = 0;                    // live key views (root only)
+  bool dying = false;               // destroyed while views were alive: the last view to go frees the pool
+  std::mutex own_mu;  // one call at a time per ROOT pool: a view's calls serialise with its parent's (they share streams and staging)
+  uint64_t id = g_next_handle_id.fetch_add(1);  // key of the per-thread error text (err_slot)
   bool replicated_by_rccl = false;  // how the last key reached the members (tfhe_hip_pool_key_transport)
+  // ---- root only: what the device-resident (_dev) calls and the key replication share ----
+  std::vector<ncclComm_t> comms;    // ONE persistent communicator per pool (created on first use, destroyed with the pool)
+  int comm_state = 0;               // 0 = not tried yet, 1 = ready, -1 = unavailable (duplicate devices, no librccl, init failed)
+  struct Stage {                    // per member: staging for shards that arrive from / leave for another member's GPU
+    DevBuf in[5], out;
+    hipEvent_t done = nullptr;      // recorded on the member's stream when its shard's result has left
+  };
+  std::vector<Stage> stage;
+  hipEvent_t ready = nullptr;       // recorded on the home stream when the call's operands are ready (peer-copy path)
+  int ready_device = -1;
+  const char *last_transport = "none";  // transport of the last _dev call: "rccl" / "peer-copy" / "none" (nothing moved)
+  // transfer timing (tfhe_hip_pool_get_transfer_times): event pairs on the receiving stream, per moved shard
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_scatter, ev_gather;
+  std::vector<int> ev_scatter_dev, ev_gather_dev;
+  uint64_t scatter_bytes = 0, gather_bytes = 0, dev_calls = 0;
+
+  tfhe_hip_pool *root() { return parent ? parent : this; }
+  const tfhe_hip_pool *root() const { return parent ? parent : this; }
 };
 
 namespace {
@@ -31,7 +54,7 @@ inline void pool_shard(size_t count, int r, int world, size_t &lo, size_t &hi) {
 }
 
 int pool_fail(tfhe_hip_pool *p, int code, const std::string &msg) {
-  p->err = msg;
+  err_slot(p->id) = msg;
   return code;
 }
 
@@ -61,12 +84,15 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   return TFHE_HIP_OK;
 }
 
-// ---- key replication by RCCL broadcast (xGMI), when the pool's devices are distinct -------------------------
-// north_star: "RCCL over xGMI used only for the trivial scatter/gather": the one exchange this path has is the
-// replication of the cloud key (172 MB, once per key).  librccl is opened at run time (no link-time dependency: a
-// process that already carries torch's RCCL reuses it by SONAME); one communicator per pool, one grouped
-// ncclBroadcast per key buffer, in place in the engine layouts.  Anything that fails -- library absent, duplicate
-// devices (ncclCommInitAll refuses them), a transport error -- falls back to the serial hipMemcpyPeer path below.
+// ---- RCCL over xGMI: one persistent communicator per pool -------------------------------------------------------
+// north_star: "RCCL over xGMI used only for the trivial scatter/gather".  The exchanges this path has are the
+// replication of the cloud key (172 MB, once per key: one grouped ncclBroadcast per key buffer, in place in the
+// engine layouts) and, for a batch that is resident on ONE member's GPU (the *_dev pool calls below), the scatter of
+// its shards and the gather of their results (grouped ncclSend / ncclRecv, one pair per peer, so all xGMI links run
+// concurrently).  librccl is opened at run time (no link-time dependency: a process that already carries torch's
+// RCCL reuses it by SONAME).  The communicator is created on first use and lives as long as the pool.  Anything that
+// fails -- library absent, duplicate devices (ncclCommInitAll refuses them), a transport error -- falls back to
+// hipMemcpyPeer[Async].
 struct RcclApi {
   void *lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
@@ -74,6 +100,8 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   bool ok = false;
 };
 inline RcclApi &rccl_api() {
@@ -89,10 +117,48 @@ inline RcclApi &rccl_api() {
     r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
-    r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast;
+    r.Send = (decltype(r.Send))dlsym(r.lib, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(r.lib, "ncclRecv");
+    r.ok = r.CommInitAll && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Broadcast && r.Send && r.Recv;
     return r;
   }();
   return a;
+}
+
+inline int pool_rccl_mode() {  // 0 = never, 1 = pools of >= 2 distinct devices, 2 = also a pool of one (plumbing test)
+  const char *env = getenv("TFHE_HIP_POOL_RCCL");
+  return env ? atoi(env) : 1;
+}
+
+// The pool's communicator (root pool's mutex held): created once, reused by every key replication and every
+// device-resident batch call, destroyed by tfhe_hip_pool_destroy.  nullptr: take the peer-copy path.
+std::vector<ncclComm_t> *pool_comms(tfhe_hip_pool *p) {
+  tfhe_hip_pool *root = p->root();
+  if (root->comm_state == 1) return &root->comms;
+  if (root->comm_state < 0) return nullptr;
+  root->comm_state = -1;
+  const int n = (int)root->ctxs.size();
+  const int mode = pool_rccl_mode();
+  if (mode == 0 || n < (mode >= 2 ? 1 : 2)) return nullptr;
+  RcclApi &R = rccl_api();
+  if (!R.ok) return nullptr;
+  std::vector<int> devs;
+  for (auto *c : root->ctxs) devs.push_back(c->device);
+  for (int i = 0; i < n; ++i)  // one rank per GPU: a pool that repeats a device takes the peer-copy path
+    for (int j = i + 1; j < n; ++j)
+      if (devs[(size_t)i] == devs[(size_t)j]) return nullptr;
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  const bool good = R.CommInitAll(comms.data(), n, devs.data()) == ncclSuccess;
+  if (prev >= 0) (void)hipSetDevice(prev);
+  if (!good) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  root->comms = std::move(comms);
+  root->comm_state = 1;
+  return &root->comms;
 }
 
 // member i >= 1: drained, its key buffers allocated, no valid key until finish_replica
@@ -121,32 +187,26 @@ int finish_replica(tfhe_hip_ctx *member, uint32_t offset) {
 }
 
 // true: every member holds member 0's key.  false: nothing usable happened (members >= 1 may hold garbage and are
-// marked unloaded): the caller takes the peer-copy path.
+// marked unloaded): the caller takes the peer-copy path.  The root pool's mutex is held by the caller, which keeps
+// every other pool call (the parent's and its views': they share that mutex) off the members' streams meanwhile.
 bool replicate_key_rccl(tfhe_hip_pool *p) {
   const int n = (int)p->ctxs.size();
-  const char *env = getenv("TFHE_HIP_POOL_RCCL");
-  const int mode = env ? atoi(env) : 1;  // 0 = never, 1 = pools of >= 2 members, 2 = also a pool of one (plumbing test)
-  if (mode == 0 || n < (mode >= 2 ? 1 : 2)) return false;
+  std::vector<ncclComm_t> *comms = pool_comms(p);
+  if (!comms) return false;
   RcclApi &R = rccl_api();
-  if (!R.ok) return false;
-  std::vector<int> devs;
-  for (auto *c : p->ctxs) devs.push_back(c->device);
-  for (int i = 0; i < n; ++i)  // one rank per GPU: a pool that repeats a device takes the peer-copy path
-    for (int j = i + 1; j < n; ++j)
-      if (devs[(size_t)i] == devs[(size_t)j]) return false;
   for (int i = 1; i < n; ++i)
     if (prepare_replica(p->ctxs[(size_t)i]) != TFHE_HIP_OK) return false;
   int prev = -1;
   (void)hipGetDevice(&prev);
-  std::vector<ncclComm_t> comms((size_t)n, nullptr);
-  if (R.CommInitAll(comms.data(), n, devs.data()) != ncclSuccess) {
-    (void)hipGetLastError();
-    if (prev >= 0) (void)hipSetDevice(prev);
-    return false;
-  }
   const tfhe_hip_params &P = p->ctxs[0]->P;
   const size_t bytes[3] = {(size_t)P.n * 2 * P.l * 2 * kN * sizeof(double),
                            (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4, (size_t)2 * kN * 4};
+  // the members' own mutexes: a member borrowed with tfhe_hip_pool_ctx() and used from another thread waits
+  std::vector<std::unique_lock<std::mutex>> held;
+  for (int i = 0; i < n; ++i) {
+    tfhe_hip_ctx *c = p->ctxs[(size_t)i];
+    held.emplace_back((c->parent ? c->parent : c)->mu);
+  }
   bool good = true;
   for (int b = 0; b < 3 && good; ++b) {
     good = R.GroupStart() == ncclSuccess;
@@ -156,7 +216,7 @@ bool replicate_key_rccl(tfhe_hip_pool *p) {
       KeyState &k = c->own;
       void *buf = b == 0 ? (void *)k.d_bsk : b == 1 ? (void *)k.d_ksk : (void *)k.d_testvec;
       good = hipSetDevice(c->device) == hipSuccess &&
-             R.Broadcast(buf, buf, bytes[b], ncclUint8, 0, comms[(size_t)i], base->stream) == ncclSuccess;
+             R.Broadcast(buf, buf, bytes[b], ncclUint8, 0, (*comms)[(size_t)i], base->stream) == ncclSuccess;
     }
     good = (R.GroupEnd() == ncclSuccess) && good;
   }
@@ -164,8 +224,8 @@ bool replicate_key_rccl(tfhe_hip_pool *p) {
     tfhe_hip_ctx *c = p->ctxs[(size_t)i];
     tfhe_hip_ctx *base = c->parent ? c->parent : c;
     if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(base->stream) != hipSuccess) good = false;
-    (void)R.CommDestroy(comms[(size_t)i]);
   }
+  held.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
   if (!good) {
     (void)hipGetLastError();
@@ -187,7 +247,6 @@ int replicate_key(tfhe_hip_pool *p) {
   return TFHE_HIP_OK;
 }
 
-// run(ctx, lo, hi) on every non-empty shard, shard 0 on the calling thread; first failure wins
 // Members a batch of `count` is spread over: one device runs up to 256 ciphertexts in the time of one (the
 // latency kernels give every ciphertext its own workgroup), so smaller batches are not cut thinner than that.
 inline int pool_world_for(const tfhe_hip_pool *p, size_t count) {
@@ -196,30 +255,268 @@ inline int pool_world_for(const tfhe_hip_pool *p, size_t count) {
   return (int)(want < 1 ? 1 : (want < have ? want : have));
 }
 
+// run(ctx, lo, hi) on every non-empty shard, shard 0 on the calling thread; first failure wins.  A shard's error text
+// is read on the thread that ran it (the text is per thread, err_slot).
 template <class F>
 int pool_map(tfhe_hip_pool *p, size_t count, F &&run) {
   const int world = pool_world_for(p, count);
   std::vector<int> rc((size_t)world, TFHE_HIP_OK);
+  std::vector<std::string> text((size_t)world);
+  auto shard = [&](int r, size_t lo, size_t hi) {
+    tfhe_hip_ctx *c = p->ctxs[(size_t)r];
+    rc[(size_t)r] = run(c, lo, hi);
+    if (rc[(size_t)r] != TFHE_HIP_OK) text[(size_t)r] = tfhe_hip_last_error(c);
+  };
   std::vector<std::thread> th;
   for (int r = 1; r < world; ++r) {
     size_t lo, hi;
     pool_shard(count, r, world, lo, hi);
     if (hi <= lo) continue;
     try {
-      th.emplace_back([&, r, lo, hi] { rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi); });
+      th.emplace_back([&, r, lo, hi] { shard(r, lo, hi); });
     } catch (const std::system_error &) {  // no thread to be had: this shard runs on the calling thread
-      rc[(size_t)r] = run(p->ctxs[(size_t)r], lo, hi);
+      shard(r, lo, hi);
     }
   }
   {
     size_t lo, hi;
     pool_shard(count, 0, world, lo, hi);
-    if (hi > lo) rc[0] = run(p->ctxs[0], lo, hi);
+    if (hi > lo) shard(0, lo, hi);
   }
   for (auto &t : th) t.join();
   for (int r = 0; r < world; ++r)
     if (rc[(size_t)r] != TFHE_HIP_OK)
-      return pool_fail(p, rc[(size_t)r], "device " + std::to_string(p->ctxs[(size_t)r]->device) + ": " + tfhe_hip_last_error(p->ctxs[(size_t)r]));
+      return pool_fail(p, rc[(size_t)r], "device " + std::to_string(p->ctxs[(size_t)r]->device) + ": " + text[(size_t)r]);
+  return TFHE_HIP_OK;
+}
+
+// ---- a batch that is RESIDENT on one member's GPU (the *_dev pool calls) ---------------------------------------
+// "scatter inputs / gather outputs as grouped ncclSend / ncclRecv when the batch is resident on one
+// GPU".  The caller's operands and result are device pointers on member `home`'s GPU and the call is only
+// ENQUEUED (like the single-context *_dev calls): on `stream` (home) and on the other members' own streams, tied
+// together by events / by the RCCL kernels themselves.  Shard r of the order-preserving split runs on member
+// (home + r) mod size, so shard 0 -- and a batch too small to be cut -- never leaves home.  Per call:
+//   home stream   [ sends of shards 1.. ]  [ shard 0 computed in place ]  [ receives of results 1.. ]
+//   peer stream   [ receive shard ]        [ compute from / into staging ] [ send result ]
+// One grouped ncclSend/ncclRecv per (peer, operand): every xGMI link carries its own peer's shard concurrently
+// (65,536 NAND over 8 GPUs: 2 x 23 MB in, 23 MB out per peer = 0.45 ms at 153 GB/s, against 42 ms of compute).
+// Without a communicator (a repeated device, no librccl, TFHE_HIP_POOL_RCCL=0): hipMemcpyPeerAsync on the peer's
+// stream behind an event of the home stream, and an event per peer ahead of whatever follows on the home stream.
+struct PoolIn {
+  const void *ptr = nullptr;  // on home's GPU; nullptr = operand absent
+  size_t row_bytes = 0;       // per ciphertext when sharded, the whole operand otherwise
+  bool sharded = true;        // false: every member needs all of it (a shared test vector)
+};
+
+// op(ctx, ins[5], out, m, stream): enqueue the batched operation for m ciphertexts on member `ctx`
+template <class Op>
+int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const PoolIn (&ins)[5], void *out,
+                 size_t out_row_bytes, Op &&op) {
+  tfhe_hip_pool *root = p->root();
+  const int size = (int)p->ctxs.size();
+  if (home < 0 || home >= size) return pool_fail(p, TFHE_HIP_EINVAL, "no such pool member (home)");
+  root->last_transport = "none";
+  if (count == 0) return TFHE_HIP_OK;
+  tfhe_hip_ctx *hctx = p->ctxs[(size_t)home];
+  tfhe_hip_ctx *hbase = hctx->parent ? hctx->parent : hctx;
+  hipStream_t hs = stream_v ? (hipStream_t)stream_v : hbase->stream;
+  const int world = pool_world_for(p, count);
+  std::vector<ncclComm_t> *comms = world > 1 || pool_rccl_mode() >= 2 ? pool_comms(p) : nullptr;
+  // TFHE_HIP_POOL_RCCL=2 on a pool of ONE member (plumbing test on a one-GPU box): home's own shard takes the remote
+  // path through a self send / receive, so the same symbols, group structure and stream handling run as among peers
+  const bool loopback = comms && size == 1 && pool_rccl_mode() >= 2;
+  const bool any_remote = world > 1 || loopback;
+  RcclApi &R = rccl_api();
+  if (root->stage.size() < (size_t)size) root->stage.resize((size_t)size);
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  struct Restore {
+    int d;
+    ~Restore() {
+      if (d >= 0) (void)hipSetDevice(d);
+    }
+  } restore{prev};
+  auto hipfail = [&](const char *what, hipError_t e, int member) {
+    return pool_fail(p, TFHE_HIP_EHIP, "device " + std::to_string(p->ctxs[(size_t)member]->device) + ": " + what + ": " + hipGetErrorString(e));
+  };
+  auto ensure_on = [&](int member, DevBuf &b, size_t bytes) -> int {
+    if (bytes <= b.cap) return TFHE_HIP_OK;
+    hipError_t e = hipSetDevice(p->ctxs[(size_t)member]->device);
+    if (e != hipSuccess) return hipfail("hipSetDevice", e, member);
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    const size_t want = bytes + bytes / 4;
+    e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return pool_fail(p, TFHE_HIP_ENOMEM, "device " + std::to_string(p->ctxs[(size_t)member]->device) + ": hipMalloc pool staging");
+    }
+    b.cap = want;
+    return TFHE_HIP_OK;
+  };
+  auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, int member, hipStream_t s, bool begin) {
+    if (!root->timing) return;
+    (void)hipSetDevice(p->ctxs[(size_t)member]->device);
+    if (begin) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      (void)hipEventRecord(a, s);
+      v.emplace_back(a, b);
+      devs.push_back(member);
+    } else if (!v.empty()) {
+      (void)hipEventRecord(v.back().second, s);
+    }
+  };
+  // shard table: shard r -> member, [lo, hi), remote?
+  struct Sh {
+    int member;
+    size_t lo, hi;
+    bool remote;
+  };
+  std::vector<Sh> shards;
+  for (int r = 0; r < world; ++r) {
+    size_t lo, hi;
+    pool_shard(count, r, world, lo, hi);
+    if (hi <= lo) continue;
+    const int member = (home + r) % size;
+    shards.push_back({member, lo, hi, member != home || loopback});
+  }
+  // 1. staging on the receiving members
+  for (const Sh &sh : shards) {
+    if (!sh.remote) continue;
+    tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+    for (int k = 0; k < 5; ++k)
+      if (ins[k].ptr) CHK(ensure_on(sh.member, st.in[k], ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes));
+    CHK(ensure_on(sh.member, st.out, (sh.hi - sh.lo) * out_row_bytes));
+    if (!st.done) {
+      (void)hipSetDevice(p->ctxs[(size_t)sh.member]->device);
+      const hipError_t e = hipEventCreateWithFlags(&st.done, hipEventDisableTiming);
+      if (e != hipSuccess) return hipfail("hipEventCreate", e, sh.member);
+    }
+  }
+  auto member_stream = [&](int member) {
+    tfhe_hip_ctx *c = p->ctxs[(size_t)member];
+    return (c->parent ? c->parent : c)->stream;
+  };
+  // 2. scatter
+  if (any_remote) {
+    root->last_transport = comms ? "rccl" : "peer-copy";
+    if (comms) {
+      if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (scatter)");
+      bool good = true;
+      for (const Sh &sh : shards) {
+        if (!sh.remote) continue;
+        tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, member_stream(sh.member), true);
+        for (int k = 0; k < 5 && good; ++k) {
+          if (!ins[k].ptr) continue;
+          const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
+          const unsigned char *src = (const unsigned char *)ins[k].ptr + (ins[k].sharded ? sh.lo * ins[k].row_bytes : 0);
+          good = hipSetDevice(hctx->device) == hipSuccess &&
+                 R.Send(src, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hs) == ncclSuccess &&
+                 hipSetDevice(p->ctxs[(size_t)sh.member]->device) == hipSuccess &&
+                 R.Recv(st.in[k].p, bytes, ncclUint8, home, (*comms)[(size_t)sh.member], member_stream(sh.member)) == ncclSuccess;
+          root->scatter_bytes += bytes;
+        }
+      }
+      good = (R.GroupEnd() == ncclSuccess) && good;
+      if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL scatter (ncclSend / ncclRecv) failed");
+      for (const Sh &sh : shards)
+        if (sh.remote) timed(root->ev_scatter, root->ev_scatter_dev, sh.member, member_stream(sh.member), false);
+    } else {
+      hipError_t e = hipSetDevice(hctx->device);
+      if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
+      if (!root->ready || root->ready_device != hctx->device) {
+        if (root->ready) (void)hipEventDestroy(root->ready);
+        root->ready = nullptr;
+        if ((e = hipEventCreateWithFlags(&root->ready, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e, home);
+        root->ready_device = hctx->device;
+      }
+      if ((e = hipEventRecord(root->ready, hs)) != hipSuccess) return hipfail("hipEventRecord", e, home);
+      for (const Sh &sh : shards) {
+        if (!sh.remote) continue;
+        tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+        const int ddev = p->ctxs[(size_t)sh.member]->device;
+        hipStream_t ms = member_stream(sh.member);
+        if ((e = hipSetDevice(ddev)) != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
+        if ((e = hipStreamWaitEvent(ms, root->ready, 0)) != hipSuccess) return hipfail("hipStreamWaitEvent", e, sh.member);
+        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, ms, true);
+        for (int k = 0; k < 5; ++k) {
+          if (!ins[k].ptr) continue;
+          const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
+          const unsigned char *src = (const unsigned char *)ins[k].ptr + (ins[k].sharded ? sh.lo * ins[k].row_bytes : 0);
+          if ((e = hipMemcpyPeerAsync(st.in[k].p, ddev, src, hctx->device, bytes, ms)) != hipSuccess)
+            return hipfail("hipMemcpyPeerAsync (scatter)", e, sh.member);
+          root->scatter_bytes += bytes;
+        }
+        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, ms, false);
+      }
+    }
+  }
+  // 3. compute: remote shards first (their members are idle until then), home's own shard last
+  for (int pass = 0; pass < 2; ++pass)
+    for (const Sh &sh : shards) {
+      if ((pass == 0) != sh.remote) continue;
+      const void *ptrs[5];
+      void *o;
+      if (sh.remote) {
+        tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+        for (int k = 0; k < 5; ++k) ptrs[k] = ins[k].ptr ? st.in[k].p : nullptr;
+        o = st.out.p;
+      } else {
+        for (int k = 0; k < 5; ++k)
+          ptrs[k] = ins[k].ptr ? (const unsigned char *)ins[k].ptr + (ins[k].sharded ? sh.lo * ins[k].row_bytes : 0) : nullptr;
+        o = (unsigned char *)out + sh.lo * out_row_bytes;
+      }
+      tfhe_hip_ctx *c = p->ctxs[(size_t)sh.member];
+      const int rc = op(c, ptrs, o, sh.hi - sh.lo, sh.remote ? (void *)member_stream(sh.member) : (void *)hs);
+      if (rc != TFHE_HIP_OK)
+        return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + tfhe_hip_last_error(c));
+    }
+  // 4. gather
+  if (any_remote) {
+    if (comms) {
+      if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (gather)");
+      bool good = true;
+      timed(root->ev_gather, root->ev_gather_dev, home, hs, true);
+      for (const Sh &sh : shards) {
+        if (!sh.remote || !good) continue;
+        tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+        const size_t bytes = (sh.hi - sh.lo) * out_row_bytes;
+        good = hipSetDevice(p->ctxs[(size_t)sh.member]->device) == hipSuccess &&
+               R.Send(st.out.p, bytes, ncclUint8, home, (*comms)[(size_t)sh.member], member_stream(sh.member)) == ncclSuccess &&
+               hipSetDevice(hctx->device) == hipSuccess &&
+               R.Recv((unsigned char *)out + sh.lo * out_row_bytes, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hs) == ncclSuccess;
+        root->gather_bytes += bytes;
+      }
+      good = (R.GroupEnd() == ncclSuccess) && good;
+      if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL gather (ncclSend / ncclRecv) failed");
+      timed(root->ev_gather, root->ev_gather_dev, home, hs, false);
+    } else {
+      for (const Sh &sh : shards) {
+        if (!sh.remote) continue;
+        tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
+        const int sdev = p->ctxs[(size_t)sh.member]->device;
+        hipStream_t ms = member_stream(sh.member);
+        const size_t bytes = (sh.hi - sh.lo) * out_row_bytes;
+        hipError_t e = hipSetDevice(sdev);
+        if (e != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
+        timed(root->ev_gather, root->ev_gather_dev, sh.member, ms, true);
+        if ((e = hipMemcpyPeerAsync((unsigned char *)out + sh.lo * out_row_bytes, hctx->device, st.out.p, sdev, bytes, ms)) != hipSuccess)
+          return hipfail("hipMemcpyPeerAsync (gather)", e, sh.member);
+        timed(root->ev_gather, root->ev_gather_dev, sh.member, ms, false);
+        if ((e = hipEventRecord(st.done, ms)) != hipSuccess) return hipfail("hipEventRecord", e, sh.member);
+        root->gather_bytes += bytes;
+      }
+      hipError_t e = hipSetDevice(hctx->device);
+      if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
+      for (const Sh &sh : shards)
+        if (sh.remote && (e = hipStreamWaitEvent(hs, root->stage[(size_t)sh.member].done, 0)) != hipSuccess)
+          return hipfail("hipStreamWaitEvent", e, home);
+    }
+  }
+  ++root->dev_calls;
   return TFHE_HIP_OK;
 }
 
@@ -253,17 +550,67 @@ int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int 
 
 void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
   if (!p) return;
+  if (p->parent) {  // a key view: its keys go, everything else is the parent's
+    tfhe_hip_pool *root = p->parent;
+    bool last_of_dying = false;
+    {
+      std::lock_guard<std::mutex> lk(root->own_mu);
+      for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);  // (drains the member's queued work first)
+      last_of_dying = --root->views == 0 && root->dying;
+    }
+    t_errors.erase(p->id);
+    delete p;
+    if (last_of_dying) tfhe_hip_pool_destroy(root);  // the parent was destroyed first: it has waited for its views
+    return;
+  }
+  {
+    // destroyed before its views (the header asks for the opposite order): they share this pool's mutex, staging and
+    // communicator, so it stays alive until the last of them goes
+    std::lock_guard<std::mutex> lk(p->own_mu);
+    if (p->views > 0) {
+      p->dying = true;
+      return;
+    }
+  }
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  // queued device-resident calls may still use the staging buffers and the communicator: drain the members first
+  for (auto *c : p->ctxs) {
+    if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+  }
+  if (p->comm_state == 1)
+    for (ncclComm_t c : p->comms)
+      if (c) (void)rccl_api().CommDestroy(c);
+  for (size_t i = 0; i < p->stage.size() && i < p->ctxs.size(); ++i) {
+    (void)hipSetDevice(p->ctxs[i]->device);
+    for (DevBuf &b : p->stage[i].in)
+      if (b.p) (void)hipFree(b.p);
+    if (p->stage[i].out.p) (void)hipFree(p->stage[i].out.p);
+    if (p->stage[i].done) (void)hipEventDestroy(p->stage[i].done);
+  }
+  if (p->ready) (void)hipEventDestroy(p->ready);
+  for (auto *v : {&p->ev_scatter, &p->ev_gather})
+    for (auto &e : *v) {
+      (void)hipEventDestroy(e.first);
+      (void)hipEventDestroy(e.second);
+    }
+  if (prev >= 0) (void)hipSetDevice(prev);
   for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);
+  t_errors.erase(p->id);
   delete p;
 }
 
-// A key view of a pool: one key view per member context (same devices, same streams and scratch, its own cloud key).
+// A key view of a pool: one key view per member context (same devices, same streams and scratch, its own cloud key);
+// it shares the parent's mutex, staging buffers and communicator.
 int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **out) {
   if (!out) return TFHE_HIP_EINVAL;
   *out = nullptr;
   if (!pool) return TFHE_HIP_EINVAL;
+  tfhe_hip_pool *root = pool->root();
+  std::lock_guard<std::mutex> lk(root->own_mu);
   tfhe_hip_pool *v = new tfhe_hip_pool();
-  for (auto *c : pool->ctxs) {
+  v->parent = root;
+  for (auto *c : root->ctxs) {
     tfhe_hip_ctx *kv = nullptr;
     const int rc = tfhe_hip_key_create(c, &kv);
     if (rc != TFHE_HIP_OK) {
@@ -273,6 +620,7 @@ int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **out) {
     }
     v->ctxs.push_back(kv);
   }
+  ++root->views;
   *out = v;
   return TFHE_HIP_OK;
 }
@@ -283,11 +631,14 @@ tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
   return (p && i >= 0 && (size_t)i < p->ctxs.size()) ? p->ctxs[(size_t)i] : nullptr;
 }
 
-const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? p->err.c_str() : g_create_error.c_str(); }
+const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? err_slot(p->id).c_str() : g_create_error.c_str(); }
 
 // "rccl" when the pool's last cloud key reached its members by ncclBroadcast, "peer-copy" when by hipMemcpyPeer
 // (or when there was nothing to replicate).
 const char *tfhe_hip_pool_key_transport(const tfhe_hip_pool *p) { return (p && p->replicated_by_rccl) ? "rccl" : "peer-copy"; }
+
+// how the last device-resident (_dev) call moved its shards: "rccl", "peer-copy", or "none" (nothing left home)
+const char *tfhe_hip_pool_data_transport(const tfhe_hip_pool *p) { return p ? p->root()->last_transport : "none"; }
 
 int tfhe_hip_pool_members_for(const tfhe_hip_pool *p, size_t count) { return p ? pool_world_for(p, count) : 0; }
 
@@ -300,7 +651,7 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 
 #define POOL_ENTER(p)               \
   if (!(p)) return TFHE_HIP_EINVAL; \
-  std::lock_guard<std::mutex> plk_((p)->mu)
+  std::lock_guard<std::mutex> plk_((p)->root()->own_mu)
 #define POOL_FIRST(p, call)                                                                                        \
   do {                                                                                                             \
     const int rc_ = (call);                                                                                        \
@@ -345,6 +696,7 @@ int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *p, int member, double *bsk, ui
   return TFHE_HIP_OK;
 }
 
+// ---- host-pointer batch calls: one host thread per shard ---------------------------------------------------------
 int tfhe_hip_pool_batch_gate(tfhe_hip_pool *p, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
                              size_t count) {
   POOL_ENTER(p);
@@ -365,6 +717,16 @@ int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *p, const uint8_t *gates, cons
   });
 }
 
+int tfhe_hip_pool_batch_gates_mixed_nks(tfhe_hip_pool *p, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
+                                        uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_gates_mixed_nks(c, gates + lo, a + lo * w, b + lo * w, out + lo * w, hi - lo);
+  });
+}
+
 int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *p, const uint32_t *in, const uint32_t *testvec, int per_ct,
                                   int keyswitch, uint32_t *out, size_t count) {
   POOL_ENTER(p);
@@ -374,6 +736,29 @@ int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *p, const uint32_t *in, const ui
   return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
     return tfhe_hip_batch_bootstrap(c, in + lo * w, testvec ? testvec + lo * tvs : nullptr, per_ct, keyswitch, out + lo * w,
                                     hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_tlwe_lincomb(tfhe_hip_pool *p, uint32_t ca, const uint32_t *a, uint32_t cb, const uint32_t *b,
+                                     uint32_t cconst, uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!a || !out || (cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_tlwe_lincomb(c, ca, a + lo * w, cb, b ? b + lo * w : nullptr, cconst, out + lo * w, hi - lo);
+  });
+}
+
+int tfhe_hip_pool_batch_lincomb_bootstrap(tfhe_hip_pool *p, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                          const uint32_t *b, uint32_t cconst, const uint32_t *testvec, int per_ct,
+                                          int keyswitch, uint32_t *out, size_t count) {
+  POOL_ENTER(p);
+  if (count && (!a || !out || (cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = (size_t)p->ctxs[0]->P.n + 1;
+  const size_t tvs = (testvec && per_ct) ? (size_t)2 * kN : 0;
+  return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
+    return tfhe_hip_batch_lincomb_bootstrap(c, ca, a + lo * w, cb, b ? b + lo * w : nullptr, cconst,
+                                            testvec ? testvec + lo * tvs : nullptr, per_ct, keyswitch, out + lo * w, hi - lo);
   });
 }
 
@@ -395,6 +780,153 @@ int tfhe_hip_pool_batch_blind_rotate(tfhe_hip_pool *p, const uint32_t *in, const
   return pool_map(p, count, [&](tfhe_hip_ctx *c, size_t lo, size_t hi) {
     return tfhe_hip_batch_blind_rotate(c, in + lo * w, testvec, out_trlwe + lo * (size_t)2 * kN, hi - lo);
   });
+}
+
+// ---- device-resident batch calls: the batch lives on member `home`'s GPU (pool_dev_map) -------------------------
+int tfhe_hip_pool_batch_gate_dev(tfhe_hip_pool *p, int home, int gate, const uint32_t *a, const uint32_t *b,
+                                 uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  GatePrep gp;
+  if (!gate_prep(gate, gp)) return pool_fail(p, TFHE_HIP_EINVAL, "unknown gate");
+  if (count && (!a || !out || (gp.cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {gp.cb ? b : nullptr, w, true}, {}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_gate_dev(c, gate, (const uint32_t *)q[0], (const uint32_t *)q[1], (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_gates_mixed_dev(tfhe_hip_pool *p, int home, const uint8_t *gates, const uint32_t *a,
+                                        const uint32_t *b, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {b, w, true}, {gates, 1, true}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_gates_mixed_dev(c, (const uint8_t *)q[2], (const uint32_t *)q[0], (const uint32_t *)q[1], (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_gates_mixed_nks_dev(tfhe_hip_pool *p, int home, const uint8_t *gates, const uint32_t *a,
+                                            const uint32_t *b, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {b, w, true}, {gates, 1, true}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_gates_mixed_nks_dev(c, (const uint8_t *)q[2], (const uint32_t *)q[0], (const uint32_t *)q[1], (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_bootstrap_dev(tfhe_hip_pool *p, int home, const uint32_t *in, const uint32_t *testvec, int per_ct,
+                                      int keyswitch, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!in || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{in, w, true}, {testvec, (size_t)2 * kN * 4, testvec && per_ct}, {}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_bootstrap_dev(c, (const uint32_t *)q[0], (const uint32_t *)q[1], per_ct, keyswitch, (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_tlwe_lincomb_dev(tfhe_hip_pool *p, int home, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                         const uint32_t *b, uint32_t cconst, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!a || !out || (cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {cb ? b : nullptr, w, true}, {}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_tlwe_lincomb_dev(c, ca, (const uint32_t *)q[0], cb, (const uint32_t *)q[1], cconst, (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_lincomb_bootstrap_dev(tfhe_hip_pool *p, int home, uint32_t ca, const uint32_t *a, uint32_t cb,
+                                              const uint32_t *b, uint32_t cconst, const uint32_t *testvec, int per_ct,
+                                              int keyswitch, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!a || !out || (cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {cb ? b : nullptr, w, true}, {testvec, (size_t)2 * kN * 4, testvec && per_ct}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_lincomb_bootstrap_dev(c, ca, (const uint32_t *)q[0], cb, (const uint32_t *)q[1], cconst,
+                                                (const uint32_t *)q[2], per_ct, keyswitch, (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_mux_dev(tfhe_hip_pool *p, int home, int naive, const uint32_t *a, const uint32_t *b,
+                                const uint32_t *c3, uint32_t *out, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!a || !b || !c3 || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{a, w, true}, {b, w, true}, {c3, w, true}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out, w, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_mux_dev(c, naive, (const uint32_t *)q[0], (const uint32_t *)q[1], (const uint32_t *)q[2], (uint32_t *)o, m, s);
+  });
+}
+
+int tfhe_hip_pool_batch_blind_rotate_dev(tfhe_hip_pool *p, int home, const uint32_t *in, const uint32_t *testvec,
+                                         uint32_t *out_trlwe, size_t count, void *stream) {
+  POOL_ENTER(p);
+  if (count && (!in || !out_trlwe)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+  const size_t w = ((size_t)p->ctxs[0]->P.n + 1) * 4;
+  const PoolIn ins[5] = {{in, w, true}, {testvec, (size_t)2 * kN * 4, false}, {}, {}, {}};
+  return pool_dev_map(p, home, count, stream, ins, out_trlwe, (size_t)2 * kN * 4, [&](tfhe_hip_ctx *c, const void *const *q, void *o, size_t m, void *s) {
+    return tfhe_hip_batch_blind_rotate_dev(c, (const uint32_t *)q[0], (const uint32_t *)q[1], (uint32_t *)o, m, s);
+  });
+}
+
+// Block until every member has finished what the pool's *_dev calls enqueued (home streams passed by the caller are
+// the caller's to synchronise; the members' own streams are drained here).
+int tfhe_hip_pool_synchronize(tfhe_hip_pool *p) {
+  POOL_ENTER(p);
+  for (auto *c : p->ctxs) {
+    const int rc = tfhe_hip_synchronize(c);
+    if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + tfhe_hip_last_error(c));
+  }
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_pool_set_profiling(tfhe_hip_pool *p, int enabled) {
+  POOL_ENTER(p);
+  p->root()->timing = enabled != 0;
+  for (auto *c : p->ctxs) {
+    const int rc = tfhe_hip_set_profiling(c, enabled);
+    if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + tfhe_hip_last_error(c));
+  }
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *p, tfhe_hip_pool_transfer_times *out) {
+  if (!out) return TFHE_HIP_EINVAL;
+  POOL_ENTER(p);
+  tfhe_hip_pool *root = p->root();
+  memset(out, 0, sizeof(*out));
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, double &sum, double &mx) {
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (i < devs.size()) (void)hipSetDevice(root->ctxs[(size_t)devs[i]]->device);
+      float t = 0.f;
+      if (hipEventSynchronize(v[i].second) == hipSuccess && hipEventElapsedTime(&t, v[i].first, v[i].second) == hipSuccess) {
+        sum += (double)t;
+        if ((double)t > mx) mx = (double)t;
+      } else {
+        (void)hipGetLastError();
+      }
+      (void)hipEventDestroy(v[i].first);
+      (void)hipEventDestroy(v[i].second);
+    }
+    v.clear();
+    devs.clear();
+  };
+  drain(root->ev_scatter, root->ev_scatter_dev, out->scatter_ms_sum, out->scatter_ms_max);
+  drain(root->ev_gather, root->ev_gather_dev, out->gather_ms_sum, out->gather_ms_max);
+  if (prev >= 0) (void)hipSetDevice(prev);
+  out->scatter_bytes = root->scatter_bytes;
+  out->gather_bytes = root->gather_bytes;
+  out->calls = root->dev_calls;
+  root->scatter_bytes = root->gather_bytes = root->dev_calls = 0;
+  return TFHE_HIP_OK;
 }
 #undef POOL_ENTER
 #undef POOL_FIRST

@@ -11,8 +11,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -22,6 +24,9 @@
 
 #include "blind_rotate.hpp"
 #include "blind_rotate_wide.hpp"
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)
+#include "../../profiles/exp/blind_rotate_wide1.hpp"
+#endif
 #include "key_switch.hpp"
 #include "key_switch_mfma.hpp"
 #include "keygen.hpp"
@@ -32,6 +37,15 @@ using namespace tfhe;
 namespace {
 
 thread_local std::string g_create_error = "";
+
+// Error text is kept PER (calling thread, handle): the header promises Send + Sync use of a handle
+// (src/bootstrap/mod.rs:23), so two threads may fail on one context at the same time, and each must read its own
+// message -- not a string another thread is assigning or has freed.  Every context and pool carries an id that is
+// never reused; the text lives in a thread-local table keyed by it, and tfhe_hip_last_error() returns the calling
+// thread's entry (valid until that thread's next failing call on the same handle).
+std::atomic<uint64_t> g_next_handle_id{1};
+thread_local std::unordered_map<uint64_t, std::string> t_errors;
+inline std::string &err_slot(uint64_t id) { return t_errors[id]; }  // (references survive rehashing)
 
 constexpr int kKsG = 32;  // ciphertexts per key-switch workgroup
 
@@ -71,24 +85,27 @@ struct tfhe_hip_ctx {
   PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
   bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
   std::mutex mu;
-  std::string err = "";
+  uint64_t id = g_next_handle_id.fetch_add(1);  // key of this context's per-thread error text (err_slot)
   bool profiling = false;
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
-  bool ks_b4 = true;  // base-4 key switch streams candidate rows through an LDS ring (k_key_switch_b4)
-  int ks_sliced = 1;  // wider bases: column-sliced LDS kernel (k_key_switch_sliced); 2 = also at base 4
-  int ks_sliced_sets = 0;  // 0: accumulator sets per lane picked per launch (ks_sliced_pick_sets); else forced (24..40)
-  int ks_mfma = 1;    // base 4: int8 matrix-core key switch (k_key_switch_mfma); 2 = at every batch size
-  size_t ks_mfma_min = 64;   // smallest batch the matrix-core kernel takes (below: the split kernel)
-  int ks_mfma_ksplit = 0;    // 0: K chunks per row block picked per launch; else forced (1, 2, 4, 8, 16)
-  size_t ks_sl_chunk_min = 384;  // wider bases: smallest batch the column-sliced kernel takes (with K chunks; below: the split kernel)
-  int ks_sl_kchunks = 0;     // 0: K chunks of the column-sliced kernel picked per launch; else forced (1 ... 64, a power of two)
-  bool br_wide = true;      // small batches use the latency kernels
-  bool br_wide2 = true;     // ... in their eight-wave form (blind_rotate_wide.hpp); false: one wave per row (round 1-2)
-  size_t wide_max = 256;    // blind rotate: 2l waves per ciphertext up to this batch size (set from #CUs)
-  size_t pair_lo = 0, pair_max = 0;  // ... two ciphertexts per eight-wave workgroup (k_blind_rotate_pair) for pair_lo < count <= pair_max
+  // ---- dispatch (plan_blind_rotate / plan_key_switch below; tfhe_hip_describe_dispatch prints a plan) ----
+  // The two selectors are the supported controls (TFHE_HIP_BR_KERNEL / TFHE_HIP_KS_KERNEL, include/tfhe_hip.h):
+  // AUTO picks per batch size, anything else runs that kernel at every batch size.
+  int br_force = 0;  // BrKind + 1, 0 = auto
+  int ks_force = 0;  // KsKind + 1, 0 = auto
+  // crossovers of the automatic choice, in ciphertexts; set from the CU count at creation.  Numeric overrides exist
+  // only in -DTFHE_EXPERIMENT builds (profiles/exp/).
+  size_t wide_max = 256;      // blind rotate: one eight-wave workgroup per ciphertext up to this batch size
+  size_t pair_lo = 0, pair_max = 0;  // ... two ciphertexts per workgroup (k_blind_rotate_pair) for pair_lo < count <= pair_max
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
+  size_t ks_mfma_min = 64;    // smallest batch the matrix-core kernel takes (below: the split kernel)
+  size_t ks_sl_chunk_min = 384;  // wider bases: smallest batch the column-sliced kernel takes (with K chunks; below: the split kernel)
+  int ks_sliced_sets = 0;     // 0: accumulator sets per lane picked per launch (ks_sliced_pick_sets); else forced (24..40)
+  int ks_mfma_ksplit = 0;     // 0: K chunks per row block picked per launch; else forced (1, 2, 4, 8, 16)
+  int ks_sl_kchunks = 0;      // 0: K chunks of the column-sliced kernel picked per launch; else forced (1 ... 64, a power of two)
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
+  bool exp_wide1 = false;  // (experiment builds with -DTFHE_EXP_WIDE1: SINGLE runs the superseded one-wave-per-row kernel)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
   hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
@@ -134,7 +151,7 @@ struct KeyBind {
   KeyBind kb_((ctx), &self_->own);                                                     \
   DeviceGuard dg_((ctx)->device);                                                      \
   if (dg_.err != hipSuccess) {                                                         \
-    (ctx)->err = std::string("hipSetDevice: ") + hipGetErrorString(dg_.err);           \
+    err_slot((ctx)->id) = std::string("hipSetDevice: ") + hipGetErrorString(dg_.err);  \
     return TFHE_HIP_EHIP;                                                              \
   }
 
@@ -142,7 +159,7 @@ struct KeyBind {
   do {                                                                                      \
     hipError_t e_ = (call);                                                                 \
     if (e_ != hipSuccess) {                                                                 \
-      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+      err_slot((ctx)->id) = std::string(#call) + ": " + hipGetErrorString(e_);              \
       return TFHE_HIP_EHIP;                                                                 \
     }                                                                                       \
   } while (0)
@@ -156,7 +173,7 @@ struct KeyBind {
 namespace {
 
 int fail(tfhe_hip_ctx *ctx, int code, const std::string &msg) {
-  ctx->err = msg;
+  err_slot(ctx->id) = msg;
   return code;
 }
 
@@ -168,7 +185,7 @@ int ensure(tfhe_hip_ctx *ctx, DevBuf &b, size_t bytes) {
   size_t want = bytes + bytes / 4;
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
-    ctx->err = std::string("hipMalloc scratch: ") + hipGetErrorString(e);
+    err_slot(ctx->id) = std::string("hipMalloc scratch: ") + hipGetErrorString(e);
     return TFHE_HIP_ENOMEM;
   }
   b.cap = want;
@@ -234,17 +251,19 @@ br_kernel_t br_pair_kernel(const tfhe_hip_ctx *ctx) {
   }
 }
 
-br_kernel_t br_wide_kernel(const tfhe_hip_ctx *ctx) {
+br_kernel_t br_single_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
-  if (ctx->br_wide2) switch (ctx->P.l) {
-      case 1: return f ? k_blind_rotate_wide2<1, true> : k_blind_rotate_wide2<1, false>;
-      case 2: return f ? k_blind_rotate_wide2<2, true> : k_blind_rotate_wide2<2, false>;
-      default: return f ? k_blind_rotate_wide2<3, true> : k_blind_rotate_wide2<3, false>;
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)  // the superseded one-wave-per-row latency kernel (profiles/exp/blind_rotate_wide1.hpp)
+  if (ctx->exp_wide1) switch (ctx->P.l) {
+      case 1: return f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>;
+      case 2: return f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>;
+      default: return f ? k_blind_rotate_wide<3, true> : k_blind_rotate_wide<3, false>;
     }
+#endif
   switch (ctx->P.l) {
-    case 1: return f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>;
-    case 2: return f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>;
-    default: return f ? k_blind_rotate_wide<3, true> : k_blind_rotate_wide<3, false>;
+    case 1: return f ? k_blind_rotate_wide2<1, true> : k_blind_rotate_wide2<1, false>;
+    case 2: return f ? k_blind_rotate_wide2<2, true> : k_blind_rotate_wide2<2, false>;
+    default: return f ? k_blind_rotate_wide2<3, true> : k_blind_rotate_wide2<3, false>;
   }
 }
 
@@ -260,6 +279,70 @@ ep_kernel_t ep_kernel(const tfhe_hip_ctx *ctx) {
 }
 
 size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx->P.n); }
+
+// ---- which blind-rotation kernels a batch of `count` runs on ----------------------------------------
+// Three kernels, one arithmetic (the same per-element operations in the same order: results are the same bits
+// whichever runs, tests/test_gpu_parity.py::test_dispatch_crossovers_bit_exact):
+//   BATCH   k_blind_rotate        one wave per ciphertext, four per workgroup: the throughput kernel
+//   SINGLE  k_blind_rotate_wide2  one eight-wave workgroup per ciphertext: the latency kernel
+//   PAIR    k_blind_rotate_pair   two ciphertexts per eight-wave workgroup, half a step apart
+// A plan is at most two launches over contiguous parts of the batch.
+enum BrKind { BR_BATCH = 0, BR_SINGLE = 1, BR_PAIR = 2 };
+const char *const kBrKindName[3] = {"batch", "single", "pair"};
+struct BrPlan {
+  int nparts = 0;
+  BrKind kind[2] = {BR_BATCH, BR_BATCH};
+  size_t begin[2] = {0, 0}, count[2] = {0, 0};
+  void add(BrKind k, size_t b, size_t c) {
+    kind[nparts] = k;
+    begin[nparts] = b;
+    count[nparts] = c;
+    ++nparts;
+  }
+};
+
+BrPlan plan_blind_rotate(const tfhe_hip_ctx *ctx, size_t count) {
+  BrPlan pl;
+  if (count == 0) return pl;
+  if (ctx->br_force) {  // TFHE_HIP_BR_KERNEL: that kernel at every batch size
+    pl.add((BrKind)(ctx->br_force - 1), 0, count);
+    return pl;
+  }
+  // Small batches, N = #CUs (measured at 128 bit, profiles/exp/logs/r3x_pair_kernel.log, r3o_crossover.log):
+  // up to N ciphertexts one workgroup each (2.2 ms); N < count <= 2N two ciphertexts per workgroup, half a step apart
+  // (3.6 ms; two rounds of singles take 4.5); up to 3N the first 2N as pairs and the rest as singles (5.8; three
+  // rounds of singles 6.4, pairs alone 7.3, the batch kernel 7.0 for anything up to 4N).
+  const size_t N1 = ctx->pair_lo, N2 = ctx->pair_max;
+  const bool pairs_on = N2 > N1 && ctx->wide_max >= N1;
+  if (pairs_on && count > N1 && count <= N2) {
+    pl.add(BR_PAIR, 0, count);
+    return pl;
+  }
+  // 2N < count <= 3N: the first 2N as pairs, the rest one per workgroup (not at l = 1, where the batch kernel's first
+  // step is cheaper than a pair launch plus a single one: SECURITY_UINT4 4.3 vs 4.9 ms; l = 2: 5.1 vs 5.4, l = 3: 5.8 vs 6.9)
+  if (pairs_on && ctx->P.l >= 2 && N2 == 2 * N1 && count > N2 && count <= N2 + N1) {
+    pl.add(BR_PAIR, 0, N2);
+    pl.add(BR_SINGLE, N2, count - N2);
+    return pl;
+  }
+  if (count <= ctx->wide_max) {
+    pl.add(BR_SINGLE, 0, count);
+    return pl;
+  }
+  // The batch kernel's time is a staircase with a step every 4N (one more four-wave workgroup per CU: 6.9 / 11.5 /
+  // 17.1 / 21.8 ms at 1,024 / 2,048 / 3,072 / 4,096).  A tail of up to 2N ciphertexts above a step is cheaper as a
+  // latency-kernel launch of its own (2.2 ms up to N, 3.6 up to 2N) than as a whole further step (1,100: 9.1 vs 10.8
+  // ms, 2,200: 14.4 vs 17.9, 3,300: 19.7 vs 22.9); done up to 32N, beyond which the step is a few per cent of the launch.
+  // (at l = 1 a pair launch costs as much as the step it would save: tails of up to N only)
+  size_t tail = 0;
+  if (pairs_on && ctx->br_chunk == 0 && count <= 32 * N1) {
+    const size_t r = count % (4 * N1);
+    if (r > 0 && r <= (ctx->P.l == 1 ? N1 : N2) && count > r) tail = r;
+  }
+  pl.add(BR_BATCH, 0, count - tail);
+  if (tail) pl.add(tail <= N1 ? BR_SINGLE : BR_PAIR, count - tail, tail);
+  return pl;
+}
 
 int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, const uint32_t *in_b,
                         GatePrep gp, const uint32_t *testvec, int per_ct, size_t count,
@@ -292,11 +375,6 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   if (out_ext2 && ctx->P.n > kN)
     return fail(ctx, TFHE_HIP_EINVAL, "bootstrap without key switch needs n <= N (sample_extract_index_2)");
   if (gp.cb && !in_b) return fail(ctx, TFHE_HIP_EINVAL, "second gate operand is NULL");
-  // Small batches (latency kernels).  Eight-wave form, N = #CUs: up to N ciphertexts one workgroup each (2.2 ms at
-  // 128 bit); N < count <= 2N two ciphertexts per workgroup, half a step apart (3.6 ms; two rounds of the former take
-  // 4.5); up to 3N the first 2N as pairs and the rest as singles (5.8; three rounds of singles 6.4, pairs alone 7.3,
-  // the batch kernel 7.0 for anything up to 4N) -- profiles/exp/logs/r3x_pair_kernel.log.  wide_max / pair_lo /
-  // pair_max hold those bounds.
   // ciphertexts [done, done + m) of this call as a launch of their own
   auto part = [&](size_t done, size_t m) {
     BlindRotateArgs S = A;
@@ -310,89 +388,47 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     S.count = m;
     return S;
   };
-  auto launch_pair = [&](const BlindRotateArgs &S) -> int {
+  auto launch = [&](br_kernel_t kern, unsigned grid, unsigned threads, size_t lds, const BlindRotateArgs &S) -> int {
     CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(br_pair_kernel(ctx), dim3((unsigned)((S.count + 1) / 2)), dim3(64u * kPairWaves),
-                       blind_rotate_pair_lds_bytes(ctx->P.n), s, S);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), lds, s, S);
     HIPCHK(ctx, hipGetLastError());
     return record_end(ctx, s, ctx->ev_br);
   };
-  auto launch_wide = [&](const BlindRotateArgs &S) -> int {
-    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l) : blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l);
-    const unsigned wthreads = ctx->br_wide2 ? 64u * kWide2Waves : 128u * (unsigned)ctx->P.l;
-    CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(br_wide_kernel(ctx), dim3((unsigned)S.count), dim3(wthreads), wlds, s, S);
-    HIPCHK(ctx, hipGetLastError());
-    return record_end(ctx, s, ctx->ev_br);
-  };
-  const bool pairs_on = ctx->br_wide && ctx->br_wide2 && ctx->pair_max > ctx->pair_lo;
-  if (pairs_on && count > ctx->pair_lo && count <= ctx->pair_max) {
-    CHK(launch_pair(A));
-    ctx->bootstraps += count;
-    return TFHE_HIP_OK;
-  }
-  // 2N < count <= 3N: the first 2N as pairs, the rest one per workgroup (3.6 + 2.2 ms; three rounds of singles: 6.4)
-  // (not at l = 1, where the batch kernel's first step is cheaper than a pair launch plus a single one: SECURITY_UINT4
-  // 4.3 vs 4.9 ms; l = 2: 5.1 vs 5.4, l = 3: 5.8 vs 6.9)
-  if (pairs_on && ctx->P.l >= 2 && ctx->pair_max == 2 * ctx->pair_lo && count > ctx->pair_max &&
-      count <= ctx->pair_max + ctx->pair_lo) {
-    CHK(launch_pair(part(0, ctx->pair_max)));
-    CHK(launch_wide(part(ctx->pair_max, count - ctx->pair_max)));
-    ctx->bootstraps += count;
-    return TFHE_HIP_OK;
-  }
-  if (ctx->br_wide && count <= ctx->wide_max) {
-    CHK(launch_wide(A));
-    ctx->bootstraps += count;
-    return TFHE_HIP_OK;
-  }
-  // The batch kernel's time is a staircase with a step every 4N (one more four-wave workgroup
-  // per CU: 6.9 / 11.5 / 17.1 / 21.8 ms at 1,024 / 2,048 / 3,072 / 4,096).  A tail of up to 2N ciphertexts above a
-  // step is cheaper as a latency-kernel launch of its own (2.2 ms up to N, 3.6 up to 2N) than as a whole further step
-  // (1,100: 9.1 vs 10.8 ms, 2,200: 14.4 vs 17.9, 3,300: 19.7 vs 22.9 -- r3x_pair_kernel.log); done up to 32N, beyond
-  // which the step is a few per cent of the launch.
-  size_t tail = 0;
-  if (pairs_on && ctx->br_chunk == 0 && count > ctx->wide_max && count <= 32 * ctx->pair_lo) {
-    const size_t r = count % (4 * ctx->pair_lo);
-    // (at l = 1 a pair launch costs as much as the step it would save: tails of up to N only)
-    if (r > 0 && r <= (ctx->P.l == 1 ? ctx->pair_lo : ctx->pair_max) && count > r) tail = r;
-  }
-  if (tail) {
-    const size_t head = count - tail;
-    const BlindRotateArgs H = part(0, head);
-    CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(br_kernel(ctx), dim3((unsigned)((head + kBrWaves - 1) / kBrWaves)), dim3(64 * kBrWaves), br_lds_bytes(ctx), s, H);
-    HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_br));
-    if (tail <= ctx->pair_lo) CHK(launch_wide(part(head, tail)));
-    else CHK(launch_pair(part(head, tail)));
-    ctx->bootstraps += count;
-    return TFHE_HIP_OK;
-  }
-  dim3 block(64 * kBrWaves);
-  size_t lds = br_lds_bytes(ctx);
-  // Default: ONE launch of the whole batch.  The four waves of a workgroup meet at a barrier every CMUX step
-  // (blind_rotate.hpp), which keeps the resident workgroups streaming the key in near lock-step on its own:
-  // L1 86 % / L2 97 % hits, 36 GB of HBM-side traffic per 65,536 bootstraps.  TFHE_HIP_BR_CHUNK splits the
-  // batch into launches of N ciphertexts (-1: the resident set) -- the round-1 remedy for free-running
-  // one-wave workgroups, whose rounds drifted apart until the 4 MiB L2s thrashed; kept for experiments.
-  size_t chunk = count;
-  if (ctx->br_chunk > 0) chunk = (size_t)ctx->br_chunk;
-  if (ctx->br_chunk < 0) {
-    int per_cu = 0;
-    hipError_t e = hipErrorUnknown;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * kBrWaves, lds);
-    if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * kBrWaves;
-  }
-  if (chunk == 0 || chunk > count) chunk = count;
-  for (size_t done = 0; done < count; done += chunk) {
-    const size_t m = (count - done < chunk) ? count - done : chunk;
-    const BlindRotateArgs S = part(done, m);
-    dim3 grid((unsigned)((m + kBrWaves - 1) / kBrWaves));
-    CHK(record_begin(ctx, s, ctx->ev_br));
-    hipLaunchKernelGGL(br_kernel(ctx), grid, block, lds, s, S);
-    HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_br));
+  const BrPlan pl = plan_blind_rotate(ctx, count);
+  for (int q = 0; q < pl.nparts; ++q) {
+    const size_t begin = pl.begin[q], m_all = pl.count[q];
+    if (pl.kind[q] == BR_PAIR) {
+      CHK(launch(br_pair_kernel(ctx), (unsigned)((m_all + 1) / 2), 64u * kPairWaves, blind_rotate_pair_lds_bytes(ctx->P.n),
+                 part(begin, m_all)));
+    } else if (pl.kind[q] == BR_SINGLE) {
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)
+      if (ctx->exp_wide1) {
+        CHK(launch(br_single_kernel(ctx), (unsigned)m_all, 128u * (unsigned)ctx->P.l,
+                   blind_rotate_wide_lds_bytes(ctx->P.n, ctx->P.l), part(begin, m_all)));
+        continue;
+      }
+#endif
+      CHK(launch(br_single_kernel(ctx), (unsigned)m_all, 64u * kWide2Waves, blind_rotate_wide2_lds_bytes(ctx->P.n, ctx->P.l),
+                 part(begin, m_all)));
+    } else {
+      // Default: ONE launch of the whole part.  The four waves of a workgroup meet at a barrier every CMUX step
+      // (blind_rotate.hpp), which keeps the resident workgroups streaming the key in near lock-step on its own:
+      // L1 86 % / L2 97 % hits.  (Experiment builds: TFHE_HIP_BR_CHUNK splits the batch into launches of N ciphertexts,
+      // -1: the resident set -- the round-1 remedy for free-running one-wave workgroups.)
+      const size_t lds = br_lds_bytes(ctx);
+      size_t chunk = m_all;
+      if (ctx->br_chunk > 0) chunk = (size_t)ctx->br_chunk;
+      if (ctx->br_chunk < 0) {
+        int per_cu = 0;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * kBrWaves, lds);
+        if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * kBrWaves;
+      }
+      if (chunk == 0 || chunk > m_all) chunk = m_all;
+      for (size_t done = 0; done < m_all; done += chunk) {
+        const size_t m = (m_all - done < chunk) ? m_all - done : chunk;
+        CHK(launch(br_kernel(ctx), (unsigned)((m + kBrWaves - 1) / kBrWaves), 64u * kBrWaves, lds, part(begin + done, m)));
+      }
+    }
   }
   ctx->bootstraps += count;
   return TFHE_HIP_OK;
@@ -411,25 +447,104 @@ km_kernel_t km_kernel_from(int nt) {
   else return nt == NT ? (km_kernel_t)k_key_switch_mfma<NT> : km_kernel_from<NT + 1>(nt);
 }
 km_kernel_t km_kernel(int nt) { return km_kernel_from<1>(nt); }
-bool ks_mfma_possible(const tfhe_hip_ctx *ctx) {
-  return ctx->P.basebit == 2 && ctx->P.t >= 6 && ctx->P.t <= 13 && ks_mfma_nt(ctx->P.n) != 0;
-}
-bool ks_mfma_wanted(const tfhe_hip_ctx *ctx, size_t count) {
-  if (!ctx->K->d_ksk8 || !ctx->ks_mfma) return false;
-  return ctx->ks_mfma > 1 || count >= ctx->ks_mfma_min;
+bool ks_mfma_possible(const tfhe_hip_params &P) {
+  return P.basebit == 2 && P.t >= 6 && P.t <= 13 && ks_mfma_nt(P.n) != 0;
 }
 // rows of a level-1 buffer the matrix-core kernel may read: whole 256-row workgroups
 size_t lv1_rows(size_t count) { return (count + kKmRows - 1) / kKmRows * kKmRows; }
 
+// ---- which key-switch kernel a batch of `count` runs on ----------------------------------------------
+// Integer arithmetic: every kernel returns the same bits (trgsw.rs:332-360).
+//   MFMA     k_key_switch_mfma    base 4: one-hot byte-plane contraction on the int8 matrix cores
+//   SLICED   k_key_switch_sliced  wider bases: 64-column slices of all `base` candidate rows through an LDS ring
+//   B4       k_key_switch_b4      base 4 without the matrix cores: candidate rows through a wave-private LDS ring
+//   GENERIC  k_key_switch         any set: buffer loads, 32 ciphertexts per workgroup
+//   SPLIT    k_key_switch_split   small batches: one ciphertext's walk cut over 32 workgroups
+// MFMA, SPLIT and SLICED with K chunks merge partial sums with integer atomics into a zeroed output: `atomics`.
+enum KsKind { KS_MFMA = 0, KS_SLICED = 1, KS_B4 = 2, KS_GENERIC = 3, KS_SPLIT = 4 };
+const char *const kKsKindName[5] = {"mfma", "sliced", "b4", "generic", "split"};
+struct KsPlan {
+  KsKind kind = KS_GENERIC;
+  int kparts = 1;  // MFMA: K chunks per row block; SLICED: K chunks (grid.z)
+  int sets = 0;    // SLICED: accumulator sets per lane
+  bool atomics = false;
+};
+
+bool ks_sliced_fits(const tfhe_hip_params &P) { return ks_sliced_lds_bytes(1 << P.basebit) <= 64 * 1024; }
+bool ks_b4_fits(const tfhe_hip_params &P) {
+  const int bd = ((ksk_row_words(P.n) >> 2) + 63) & ~63;
+  return P.basebit == 2 && ks_b4_lds_bytes(bd >> 6, kKsG) <= 64 * 1024;
+}
+bool ks_kind_possible(const tfhe_hip_params &P, KsKind k) {
+  switch (k) {
+    case KS_MFMA: return ks_mfma_possible(P);
+    case KS_SLICED: return ks_sliced_fits(P);
+    case KS_B4: return ks_b4_fits(P);
+    default: return true;
+  }
+}
+
+KsPlan plan_key_switch(const tfhe_hip_ctx *ctx, size_t count) {
+  const tfhe_hip_params &P = ctx->P;
+  const int n = P.n;
+  KsPlan pl;
+  const bool forced = ctx->ks_force != 0;
+  // base-4 sets from 64 ciphertexts up: the matrix-core kernel, its walk over K cut into chunks while the batch is
+  // too small to fill the chip with row blocks (0.10 / 0.11 / 0.15 / 0.18 / 0.25 / 0.40 ms at 64 / 256 / 512 / 1,024 /
+  // 2,048 / 4,096 ciphertexts; the split kernel takes 0.12 / 0.33 / 0.55 / 0.97 / 1.8 / 3.6, the matrix-core kernel
+  // without chunks 0.42-0.49 throughout: profiles/exp/logs/r3_ks_splitk.log).
+  // Wider bases from 384 ciphertexts up: the column-sliced kernel with its walk over the coefficients cut into chunks
+  // (SECURITY_UINT4: 0.37 / 0.37 / 0.57 / 1.05 ms at 512 / 1,024 / 2,048 / 4,096 ciphertexts where the split kernel
+  // takes 0.46 / 0.85 / 1.62 / 3.42 and wins below: 0.27 vs 0.29 at 256 -- profiles/exp/logs/r3_ks_sl_chunks.log).
+  // Smaller batches, and whatever neither LDS kernel covers, up to ks_split_max: the split kernel.
+  if (forced) pl.kind = (KsKind)(ctx->ks_force - 1);
+  else if (ctx->K->d_ksk8 && count >= ctx->ks_mfma_min) pl.kind = KS_MFMA;
+  else {
+    const bool sliced_ok = P.basebit != 2 && ks_sliced_fits(P);
+    if (count <= ctx->ks_split_max && !(sliced_ok && count >= ctx->ks_sl_chunk_min)) pl.kind = KS_SPLIT;
+    else if (sliced_ok) pl.kind = KS_SLICED;
+    else if (ks_b4_fits(P)) pl.kind = KS_B4;
+    else pl.kind = KS_GENERIC;
+  }
+  if (pl.kind == KS_MFMA) {
+    // one workgroup per (128 rows, column block, byte plane, K chunk); small batches have few row blocks: the walk over
+    // K is cut into up to 16 chunks so that there are about two workgroups per CU to run
+    const size_t rb = (count + kKmRows - 1) / kKmRows;
+    const int tiles = ks_mfma_total_tiles(n);
+    const size_t ncb = (size_t)(tiles < kKmColBlocks ? tiles : kKmColBlocks);
+    int ksplit = 1;
+    while (ksplit < 16 && rb * ncb * 4 * (size_t)ksplit < 2 * (size_t)ctx->num_cus) ksplit *= 2;
+    if (ctx->ks_mfma_ksplit) ksplit = ctx->ks_mfma_ksplit;
+    pl.kparts = ksplit;
+    pl.atomics = true;
+  } else if (pl.kind == KS_SLICED) {
+    // accumulator sets per lane: whichever fills whole rounds of the machine (two workgroups per CU)
+    const int slices = (n + 1 + 63) / 64, base = 1 << P.basebit;
+    int sets = ks_sliced_pick_sets(count, slices, 2 * ctx->num_cus);
+    if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
+    if (ks_sliced_lds_bytes(base, sets) > 64 * 1024) sets = kKsSlSets;
+    // small batches have few ciphertext groups: the walk over the N coefficients is cut into up to 64 chunks (grid.z)
+    // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics
+    const size_t groups = (count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
+    int kchunks = 1;
+    while (kchunks < 64 && groups * (size_t)slices * (size_t)kchunks < 2 * (size_t)ctx->num_cus) kchunks *= 2;
+    if (ctx->ks_sl_kchunks) kchunks = ctx->ks_sl_kchunks;
+    pl.sets = sets;
+    pl.kparts = kchunks;
+    pl.atomics = kchunks > 1;
+  } else if (pl.kind == KS_SPLIT) {
+    pl.kparts = 32;
+    pl.atomics = true;
+  }
+  return pl;
+}
+
 // (re)build the byte planes from the u32 engine key; called wherever a key becomes current
 int build_ksk_planes(tfhe_hip_ctx *ctx) {
-  if (!ks_mfma_possible(ctx) || !ctx->ks_mfma) return TFHE_HIP_OK;
+  if (!ks_mfma_possible(ctx->P) || (ctx->ks_force && ctx->ks_force - 1 != KS_MFMA)) return TFHE_HIP_OK;
   const tfhe_hip_params &P = ctx->P;
-  const int nt = ks_mfma_nt(P.n);
   const size_t bytes = ks_mfma_key_bytes(P.n, P.t);
   if (!ctx->K->d_ksk8) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk8, bytes + kKmKeyTailPad));
-  HIPCHK(ctx, hipFuncSetAttribute((const void *)km_kernel(nt), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)ks_mfma_lds_bytes(nt)));
   const size_t chunks = bytes / 16;
   hipLaunchKernelGGL(k_ksk_planes, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, ctx->stream, ctx->K->d_ksk,
                      ctx->K->d_ksk8, P.n, P.t, chunks);
@@ -438,133 +553,87 @@ int build_ksk_planes(tfhe_hip_ctx *ctx) {
   return TFHE_HIP_OK;
 }
 
-int launch_key_switch_mfma(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
-  const int n = ctx->P.n, nt = ks_mfma_nt(n);
-  km_kernel_t kern = km_kernel(nt);
-  // the planes are merged with integer atomics: host (pinned, zero-copy) outputs go through a device buffer
-  uint32_t *dst = out;
-  hipPointerAttribute_t at;
-  const size_t obytes = count * (size_t)(n + 1) * 4;
-  bool host_out = false;
-  if (hipPointerGetAttributes(&at, (const void *)out) != hipSuccess) {
-    (void)hipGetLastError();
-    return fail(ctx, TFHE_HIP_EINVAL, "key switch output is not GPU-addressable memory");
-  }
-  if (at.type == hipMemoryTypeHost) {
-    host_out = true;
-    CHK(ensure(ctx, ctx->ks_out, obytes));
-    dst = (uint32_t *)ctx->ks_out.p;
-  }
-  HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
-  // one workgroup per (128 rows, column block, byte plane, K chunk); consecutive workgroups walk the same key plane.
-  // Small batches have few row blocks: the walk over K is cut into up to 16 chunks so that there are about two
-  // workgroups per CU to run (a 256-ciphertext batch is 2 row blocks x 8 streams = 16 workgroups otherwise).
-  const size_t rb = (count + kKmRows - 1) / kKmRows;
-  const size_t lds = ks_mfma_lds_bytes(nt);
-  const int tiles = ks_mfma_total_tiles(n);
-  const unsigned ncb = (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks);
-  int ksplit = 1;
-  while (ksplit < 16 && rb * ncb * 4 * (size_t)ksplit < 2 * (size_t)ctx->num_cus) ksplit *= 2;
-  if (ctx->ks_mfma_ksplit) ksplit = ctx->ks_mfma_ksplit;
-  hipLaunchKernelGGL(kern, dim3((unsigned)rb * (unsigned)ksplit, ncb, 4), dim3(64 * kKmWaves), lds, s, lv1,
-                     (const unsigned char *)ctx->K->d_ksk8, n, ctx->P.t, dst, count,
-                     ctx->profiling ? ctx->d_diag + 4 : nullptr, ksplit);
-  HIPCHK(ctx, hipGetLastError());
-  if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
-  return TFHE_HIP_OK;
-}
-
 int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uint32_t *out, size_t count) {
   if (count == 0) return TFHE_HIP_OK;
-  const int n = ctx->P.n;
+  const tfhe_hip_params &P = ctx->P;
+  const int n = P.n;
+  const KsPlan pl = plan_key_switch(ctx, count);
+  if (pl.kind == KS_MFMA && !ctx->K->d_ksk8) return fail(ctx, TFHE_HIP_EINVAL, "matrix-core key switch: byte planes not built");
+  const size_t obytes = count * (size_t)(n + 1) * 4;
+  // Kernels that merge partial sums with integer atomics need a zeroed DEVICE destination: a host (pinned, zero-copy)
+  // output would take the atomics over PCIe, which not every root complex completes (AtomicOps are optional), and
+  // silently returns wrong words where it does not -- such outputs go through a device buffer and leave in one copy.
+  // Classified and allocated before the event pair opens, so that a failure here leaves no half-recorded pair behind.
+  uint32_t *dst = out;
+  bool host_out = false;
+  if (pl.atomics) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, (const void *)out) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(ctx, TFHE_HIP_EINVAL, "key switch output is not GPU-addressable memory");
+    }
+    if (at.type == hipMemoryTypeHost) {
+      host_out = true;
+      CHK(ensure(ctx, ctx->ks_out, obytes));
+      dst = (uint32_t *)ctx->ks_out.p;
+    }
+  }
   const int rw4 = ksk_row_words(n) >> 2;
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
-  dim3 grid((unsigned)((count + kKsG - 1) / kKsG)), block(bd);
+  const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(n) * 4;
   CHK(record_begin(ctx, s, ctx->ev_ks));
-  // base-4 sets from 64 ciphertexts up: the matrix-core kernel, its walk over K cut into chunks while the batch is
-  // too small to fill the chip with row blocks (0.10 / 0.11 / 0.15 / 0.18 / 0.25 / 0.40 ms at 64 / 256 / 512 / 1,024 /
-  // 2,048 / 4,096 ciphertexts; the split kernel takes 0.12 / 0.33 / 0.55 / 0.97 / 1.8 / 3.6, the matrix-core kernel
-  // without chunks 0.42-0.49 throughout: profiles/exp/logs/r3_ks_splitk.log)
-  if (ks_mfma_wanted(ctx, count)) {
-    CHK(launch_key_switch_mfma(ctx, s, lv1, out, count));
-    CHK(record_end(ctx, s, ctx->ev_ks));
-    return TFHE_HIP_OK;
-  }
-  const size_t sl_lds = ks_sliced_lds_bytes(1 << ctx->P.basebit);  // at the default S; the launch re-derives it for the S it picks
-  const bool sliced_ok = (ctx->P.basebit != 2 || ctx->ks_sliced > 1) && ctx->ks_sliced && sl_lds <= 64 * 1024;
-  // wider bases from 384 ciphertexts up: the column-sliced kernel with its walk over the coefficients cut into chunks
-  // (below; SECURITY_UINT4: 0.37 / 0.37 / 0.57 / 1.05 ms at 512 / 1,024 / 2,048 / 4,096 ciphertexts where the split
-  // kernel takes 0.46 / 0.85 / 1.62 / 3.42 and wins below: 0.27 vs 0.29 at 256 -- profiles/exp/logs/r3_ks_sl_chunks.log).
-  // Smaller batches, and whatever neither LDS kernel covers:
-  if (ctx->br_wide && count <= ctx->ks_split_max && !(sliced_ok && count >= ctx->ks_sl_chunk_min)) {
-    // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
-    const size_t kb = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
-    HIPCHK(ctx, hipMemsetAsync(out, 0, count * (size_t)(n + 1) * 4, s));
-    hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, 32), block, 0, s, lv1, (const uint4 *)ctx->K->d_ksk,
-                       (uint32_t)kb, n, ctx->P.basebit, ctx->P.t, out);
+  auto body = [&]() -> int {
+    if (pl.atomics) HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
+    switch (pl.kind) {
+      case KS_MFMA: {
+        const int nt = ks_mfma_nt(n);
+        const size_t rb = (count + kKmRows - 1) / kKmRows;
+        const int tiles = ks_mfma_total_tiles(n);
+        const unsigned ncb = (unsigned)(tiles < kKmColBlocks ? tiles : kKmColBlocks);
+        hipLaunchKernelGGL(km_kernel(nt), dim3((unsigned)rb * (unsigned)pl.kparts, ncb, 4), dim3(64 * kKmWaves),
+                           ks_mfma_lds_bytes(nt), s, lv1, (const unsigned char *)ctx->K->d_ksk8, n, P.t, dst, count,
+                           ctx->profiling ? ctx->d_diag + 4 : nullptr, pl.kparts);
+        break;
+      }
+      case KS_SPLIT:
+        // small batch: split each ciphertext's walk over 32 workgroups, merge with integer atomics
+        hipLaunchKernelGGL(k_key_switch_split, dim3((unsigned)count, (unsigned)pl.kparts), dim3(bd), 0, s, lv1,
+                           (const uint4 *)ctx->K->d_ksk, (uint32_t)ksk_bytes, n, P.basebit, P.t, dst);
+        break;
+      case KS_SLICED: {
+        const int slices = (n + 1 + 63) / 64, base = 1 << P.basebit;
+        const size_t groups = (count + (size_t)ks_sliced_cts(pl.sets) - 1) / (size_t)ks_sliced_cts(pl.sets);
+        typedef void (*sl_kernel_t)(const uint32_t *, const unsigned char *, int, int, int, uint32_t *, size_t);
+        sl_kernel_t kern = nullptr;
+        const bool ic8 = ks_sliced_stage(base) == 8;
+        switch (pl.sets) {
+          case 24: kern = ic8 ? k_key_switch_sliced<8, 24> : k_key_switch_sliced<16, 24>; break;
+          case 28: kern = ic8 ? k_key_switch_sliced<8, 28> : k_key_switch_sliced<16, 28>; break;
+          case 36: kern = ic8 ? k_key_switch_sliced<8, 36> : k_key_switch_sliced<16, 36>; break;
+          case 40: kern = ic8 ? k_key_switch_sliced<8, 40> : k_key_switch_sliced<16, 40>; break;
+          default: kern = ic8 ? k_key_switch_sliced<8, 32> : k_key_switch_sliced<16, 32>; break;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices, (unsigned)pl.kparts), dim3(256),
+                           ks_sliced_lds_bytes(base, pl.sets), s, lv1, (const unsigned char *)ctx->K->d_ksk, n, P.basebit,
+                           P.t, dst, count);
+        break;
+      }
+      case KS_B4:
+        hipLaunchKernelGGL((k_key_switch_b4<kKsG>), dim3((unsigned)((count + kKsG - 1) / kKsG)), dim3(bd),
+                           ks_b4_lds_bytes(bd >> 6, kKsG), s, lv1, (const unsigned char *)ctx->K->d_ksk, n, P.t, dst, count);
+        break;
+      default:
+        hipLaunchKernelGGL((k_key_switch<kKsG>), dim3((unsigned)((count + kKsG - 1) / kKsG)), dim3(bd), 0, s, lv1,
+                           (const uint4 *)ctx->K->d_ksk, (uint32_t)ksk_bytes, n, P.basebit, P.t, dst, count);
+        break;
+    }
     HIPCHK(ctx, hipGetLastError());
-    CHK(record_end(ctx, s, ctx->ev_ks));
+    if (host_out) HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
     return TFHE_HIP_OK;
-  }
-  const size_t ksk_bytes = (size_t)kN * ctx->P.t * (1u << ctx->P.basebit) * ksk_row_words(n) * 4;
-  const size_t b4_lds = ks_b4_lds_bytes(bd >> 6, kKsG);
-  const bool b4_fits = b4_lds <= 64 * 1024;
-  if (sliced_ok) {
-    // accumulator sets per lane: whichever fills whole rounds of the machine (two workgroups per CU)
-    const int slices = (n + 1 + 63) / 64, base = 1 << ctx->P.basebit;
-    int sets = ks_sliced_pick_sets(count, slices, 2 * ctx->num_cus);
-    if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
-    if (ks_sliced_lds_bytes(base, sets) > 64 * 1024) sets = kKsSlSets;
-    const size_t lds = ks_sliced_lds_bytes(base, sets);
-    // small batches have few ciphertext groups: the walk over the N coefficients is cut into up to 64 chunks (grid.z)
-    // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics
-    const size_t groups = (count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
-    int kchunks = 1;
-    if (ctx->br_wide)
-      while (kchunks < 64 && groups * (size_t)slices * (size_t)kchunks < 2 * (size_t)ctx->num_cus) kchunks *= 2;
-    if (ctx->ks_sl_kchunks) kchunks = ctx->ks_sl_kchunks;
-    uint32_t *dst = out;
-    bool host_out = false;
-    const size_t obytes = count * (size_t)(n + 1) * 4;
-    if (kchunks > 1) {  // atomics: host (pinned, zero-copy) outputs go through a device buffer, as for the matrix-core kernel
-      hipPointerAttribute_t at;
-      if (hipPointerGetAttributes(&at, (const void *)out) != hipSuccess) {
-        (void)hipGetLastError();
-        return fail(ctx, TFHE_HIP_EINVAL, "key switch output is not GPU-addressable memory");
-      }
-      if (at.type == hipMemoryTypeHost) {
-        host_out = true;
-        CHK(ensure(ctx, ctx->ks_out, obytes));
-        dst = (uint32_t *)ctx->ks_out.p;
-      }
-      HIPCHK(ctx, hipMemsetAsync(dst, 0, obytes, s));
-    }
-    dim3 sgrid((unsigned)groups, (unsigned)slices, (unsigned)kchunks);
-    typedef void (*sl_kernel_t)(const uint32_t *, const unsigned char *, int, int, int, uint32_t *, size_t);
-    sl_kernel_t kern = nullptr;
-    const bool ic8 = ks_sliced_stage(base) == 8;
-    switch (sets) {
-      case 24: kern = ic8 ? k_key_switch_sliced<8, 24> : k_key_switch_sliced<16, 24>; break;
-      case 28: kern = ic8 ? k_key_switch_sliced<8, 28> : k_key_switch_sliced<16, 28>; break;
-      case 36: kern = ic8 ? k_key_switch_sliced<8, 36> : k_key_switch_sliced<16, 36>; break;
-      case 40: kern = ic8 ? k_key_switch_sliced<8, 40> : k_key_switch_sliced<16, 40>; break;
-      default: kern = ic8 ? k_key_switch_sliced<8, 32> : k_key_switch_sliced<16, 32>; break;
-    }
-    hipLaunchKernelGGL(kern, sgrid, dim3(256), lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n, ctx->P.basebit, ctx->P.t,
-                       dst, count);
-    if (host_out) {
-      HIPCHK(ctx, hipGetLastError());
-      HIPCHK(ctx, hipMemcpyAsync(out, dst, obytes, hipMemcpyDefault, s));
-    }
-  } else if (ctx->P.basebit == 2 && ctx->ks_b4 && b4_fits)
-    hipLaunchKernelGGL((k_key_switch_b4<kKsG>), grid, block, b4_lds, s, lv1, (const unsigned char *)ctx->K->d_ksk, n,
-                       ctx->P.t, out, count);
-  else
-    hipLaunchKernelGGL((k_key_switch<kKsG>), grid, block, 0, s, lv1, (const uint4 *)ctx->K->d_ksk, (uint32_t)ksk_bytes,
-                       n, ctx->P.basebit, ctx->P.t, out, count);
-  HIPCHK(ctx, hipGetLastError());
-  CHK(record_end(ctx, s, ctx->ev_ks));
-  return TFHE_HIP_OK;
+  };
+  const int rc = body();
+  const int rc_end = record_end(ctx, s, ctx->ev_ks);  // the pair is closed whichever way the body ended
+  return rc != TFHE_HIP_OK ? rc : rc_end;
 }
 
 int need_key(tfhe_hip_ctx *ctx) {
@@ -769,7 +838,7 @@ const char *tfhe_hip_name(void) { return TFHE_ABLATED ? "hip-gfx950-EXPERIMENT" 
 
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
   if (ctx && ctx->parent) ctx = ctx->parent;
-  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+  return ctx ? err_slot(ctx->id).c_str() : g_create_error.c_str();
 }
 
 int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out) {
@@ -794,6 +863,38 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     g_create_error = "device ordinal out of range";
     return TFHE_HIP_EINVAL;
   }
+  // The supported controls (include/tfhe_hip.h): force ONE kernel at every batch size.  The parity suite uses them to
+  // hold every shipped kernel to the CPU checker; they never change result bits.  (Validated before anything is allocated.)
+  int br_force = 0, ks_force = 0;
+  if (const char *env = getenv("TFHE_HIP_BR_KERNEL")) {
+    const std::string v(env);
+    if (v == "batch") br_force = BR_BATCH + 1;
+    else if (v == "single") br_force = BR_SINGLE + 1;
+    else if (v == "pair") br_force = BR_PAIR + 1;
+    else if (v != "auto" && !v.empty()) {
+      g_create_error = "TFHE_HIP_BR_KERNEL must be auto, batch, single or pair";
+      return TFHE_HIP_EINVAL;
+    }
+    if (br_force == BR_PAIR + 1 && blind_rotate_pair_lds_bytes(p->n) > 160 * 1024) {
+      g_create_error = "TFHE_HIP_BR_KERNEL=pair: not available for this parameter set";
+      return TFHE_HIP_EINVAL;
+    }
+  }
+  if (const char *env = getenv("TFHE_HIP_KS_KERNEL")) {
+    const std::string v(env);
+    int k = -1;
+    for (int i = 0; i < 5; ++i)
+      if (v == kKsKindName[i]) k = i;
+    if (k < 0 && v != "auto" && !v.empty()) {
+      g_create_error = "TFHE_HIP_KS_KERNEL must be auto, mfma, sliced, b4, generic or split";
+      return TFHE_HIP_EINVAL;
+    }
+    if (k >= 0 && !ks_kind_possible(*p, (KsKind)k)) {
+      g_create_error = std::string("TFHE_HIP_KS_KERNEL=") + v + ": not available for this parameter set";
+      return TFHE_HIP_EINVAL;
+    }
+    ks_force = k + 1;
+  }
   tfhe_hip_ctx *ctx = new tfhe_hip_ctx();
   ctx->P = *p;
   ctx->device = device;
@@ -815,14 +916,25 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   ctx->num_cus = prop.multiProcessorCount;
   // pre-rounding magnitude bound: 2l polynomials x N terms x (Bg/2) digit x 2^31 key coefficient
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
+  // crossovers of the automatic dispatch, measured on the 256-CU part and kept as multiples of the CU count:
+  // key switch vs the group kernels ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced); blind rotation vs the
+  // batch kernel (7.0 ms for anything up to 1,024 ciphertexts at 128 bit): the eight-wave form takes 2.2 / 4.5 / 6.6 /
+  // 8.5 ms for 1 / 2 / 3 / 4 rounds of one workgroup per CU (profiles/exp/logs/r3o_crossover.log) -- three rounds only
+  // at l = 3: at l = 1, 2 the batch kernel's first step (4.3 / 5.4 ms) is cheaper than three rounds of singles (6.2 ms)
+  ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
+  ctx->wide_max = (p->l >= 3 ? 3 : 2) * (size_t)ctx->num_cus;
+  ctx->pair_lo = (size_t)ctx->num_cus;
+  ctx->pair_max = 2 * (size_t)ctx->num_cus;
+  if (blind_rotate_pair_lds_bytes(p->n) > 160 * 1024) ctx->pair_max = 0;  // (n > 1,900: no parameter set)
+  ctx->br_force = br_force;
+  ctx->ks_force = ks_force;
+#ifdef TFHE_EXPERIMENT
+  // Numeric overrides of the crossovers and of the per-launch choices: experiment builds only (profiles/exp/).
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
-  if (const char *env = getenv("TFHE_HIP_KS_B4")) ctx->ks_b4 = atoi(env) != 0;
-  if (const char *env = getenv("TFHE_HIP_KS_SLICED")) ctx->ks_sliced = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_SLICED_SETS")) {
     const int v = atoi(env);
     ctx->ks_sliced_sets = (v == 24 || v == 28 || v == 32 || v == 36 || v == 40) ? v : 0;
   }
-  if (const char *env = getenv("TFHE_HIP_KS_MFMA")) ctx->ks_mfma = atoi(env);
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SL_CHUNK_MIN")) ctx->ks_sl_chunk_min = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SL_KCHUNKS")) {
@@ -833,35 +945,44 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     const int v = atoi(env);
     ctx->ks_mfma_ksplit = (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ? v : 0;
   }
-  // measured crossovers vs the group kernels: ~7.8k ciphertexts (base 4, LDS ring), ~4.1k (column-sliced)
-  ctx->ks_split_max = (p->basebit == 2 ? 28 : 16) * (size_t)ctx->num_cus;
-  if (const char *env = getenv("TFHE_HIP_BR_WIDE")) ctx->br_wide = atoi(env) != 0;
-  if (const char *env = getenv("TFHE_HIP_BR_WIDE2")) ctx->br_wide2 = atoi(env) != 0;
-  // crossover vs the batch kernel (7.0 ms for anything up to 1,024 ciphertexts at 128 bit): the eight-wave form takes
-  // 2.2 / 4.5 / 6.6 / 8.5 ms for 1 / 2 / 3 / 4 rounds of one workgroup per CU, the six-wave form 3.0 / 6.1 / 9.1
-  // (profiles/exp/logs/r3o_crossover.log, r2q_crossover_latency_vs_batch.log)
-  // (three rounds only at l = 3: at l = 1, 2 the batch kernel's first step -- 4.3 / 5.4 ms -- is cheaper than three
-  // rounds of singles -- 6.2 ms)
-  ctx->wide_max = ((ctx->br_wide2 && p->l >= 3) ? 3 : 2) * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_WIDE_MAX")) ctx->wide_max = (size_t)atol(env);
-  ctx->pair_lo = (size_t)ctx->num_cus;
-  ctx->pair_max = 2 * (size_t)ctx->num_cus;
   if (const char *env = getenv("TFHE_HIP_PAIR_LO")) ctx->pair_lo = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_PAIR_MAX")) ctx->pair_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
-  // dynamic LDS above the 64 KiB default, declared once per context for the kernels of this parameter set
+#ifdef TFHE_EXP_WIDE1
+  if (const char *env = getenv("TFHE_HIP_BR_WIDE2")) ctx->exp_wide1 = atoi(env) == 0;
+#endif
+#endif
+  // Dynamic LDS above the 64 KiB default.  The attribute belongs to the (kernel, device), not to the context, and
+  // contexts of different n share an instantiation (SECURITY_80/110/128_BIT all run k_blind_rotate<3, true>): it is
+  // set to the size for the LARGEST supported n, so the order in which contexts are created cannot lower it below
+  // what an earlier context launches with.  (A launch still requests only what its own n needs.)
   {
-    const size_t lds = blind_rotate_lds_bytes(p->n);
-    const size_t wlds = ctx->br_wide2 ? blind_rotate_wide2_lds_bytes(p->n, p->l) : blind_rotate_wide_lds_bytes(p->n, p->l);
-    if ((e = hipFuncSetAttribute((const void *)br_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
+    constexpr int kMaxN = 1279;  // tfhe_hip_ctx_create's bound
+    auto set_lds = [&](const void *kern, size_t bytes) {
+      const size_t cap = 160 * 1024;
+      return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < cap ? bytes : cap));
+    };
+    if ((e = set_lds((const void *)br_kernel(ctx), blind_rotate_lds_bytes(kMaxN))) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate)", e);
-    if ((e = hipFuncSetAttribute((const void *)br_wide_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wlds)) != hipSuccess)
-      return bail("hipFuncSetAttribute(k_blind_rotate_wide)", e);
-    if (blind_rotate_pair_lds_bytes(p->n) > 160 * 1024) ctx->pair_max = 0;  // (n > 1,900: no parameter set)
-    else if ((e = hipFuncSetAttribute((const void *)br_pair_kernel(ctx), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)blind_rotate_pair_lds_bytes(p->n))) != hipSuccess)
+    if ((e = set_lds((const void *)br_single_kernel(ctx), blind_rotate_wide2_lds_bytes(kMaxN, p->l))) != hipSuccess)
+      return bail("hipFuncSetAttribute(k_blind_rotate_wide2)", e);
+    if (ctx->pair_max && (e = set_lds((const void *)br_pair_kernel(ctx), blind_rotate_pair_lds_bytes(kMaxN))) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate_pair)", e);
+    if (ks_mfma_possible(*p)) {  // one instantiation per tile count: its LDS size does not depend on n beyond that
+      const int nt = ks_mfma_nt(p->n);
+      if ((e = set_lds((const void *)km_kernel(nt), ks_mfma_lds_bytes(nt))) != hipSuccess)
+        return bail("hipFuncSetAttribute(k_key_switch_mfma)", e);
+    }
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)
+    {
+      const bool keep = ctx->exp_wide1;
+      ctx->exp_wide1 = true;
+      (void)set_lds((const void *)br_single_kernel(ctx), blind_rotate_wide_lds_bytes(kMaxN, p->l));
+      ctx->exp_wide1 = keep;
+    }
+#endif
   }
   std::vector<double2> tw;
   make_twiddles(tw);
@@ -931,6 +1052,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     if (b->p) (void)hipHostFree(b->p);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  t_errors.erase(ctx->id);
   delete ctx;
 }
 
@@ -1632,6 +1754,30 @@ int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sampl
   out->rtc_ticks = h[1];
   out->rtc_mhz = ctx->rtc_khz / 1000.0;
   out->shader_mhz = h[1] ? (double)h[0] / (double)h[1] * out->rtc_mhz : 0.0;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_describe_dispatch(tfhe_hip_ctx *ctx, size_t count, char *buf, size_t buflen) {
+  if (!ctx || !buf || buflen == 0) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  std::string d = "blind_rotate=";
+  const BrPlan bp = plan_blind_rotate(ctx, count);
+  for (int q = 0; q < bp.nparts; ++q) {
+    if (q) d += "+";
+    d += std::string(kBrKindName[bp.kind[q]]) + "[" + std::to_string(bp.begin[q]) + "," + std::to_string(bp.begin[q] + bp.count[q]) + ")";
+  }
+  if (bp.nparts == 0) d += "none";
+  d += " key_switch=";
+  if (count == 0) d += "none";
+  else {
+    const KsPlan kp = plan_key_switch(ctx, count);
+    d += kKsKindName[kp.kind];
+    if (kp.kind == KS_MFMA || kp.kind == KS_SLICED || kp.kind == KS_SPLIT) d += "(k=" + std::to_string(kp.kparts);
+    if (kp.kind == KS_SLICED) d += ",sets=" + std::to_string(kp.sets);
+    if (kp.kind == KS_MFMA || kp.kind == KS_SLICED || kp.kind == KS_SPLIT) d += ")";
+  }
+  if (d.size() + 1 > buflen) return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_describe_dispatch: buffer too small");
+  memcpy(buf, d.c_str(), d.size() + 1);
   return TFHE_HIP_OK;
 }
 

@@ -503,6 +503,13 @@ class Engine:
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))
 
+    def describe_dispatch(self, count: int) -> str:
+        """Which kernels a batch of `count` runs on (`tfhe_hip_describe_dispatch`), e.g.
+        "blind_rotate=batch[0,1024)+single[1024,1100) key_switch=mfma(k=4)".  Needs the key loaded."""
+        buf = C.create_string_buffer(256)
+        self._chk(self._lib.tfhe_hip_describe_dispatch(self._ctx, int(count), buf, len(buf)))
+        return buf.value.decode()
+
 
 class Pool:
     """Several GPUs behind one handle (`tfhe_hip_pool`): the reference's Rayon `par_map` over the ciphertexts of
@@ -527,6 +534,7 @@ class Pool:
                 msg = self._lib.tfhe_hip_pool_last_error(None)
                 raise _capi.TfheHipError(rc, msg.decode() if msg else "")
         self._h = h
+        self.home = 0  # member whose GPU holds the operands of the *_dev calls (their `home` argument's default)
         self._parent = _view_of  # keeps the parent pool alive for as long as this view exists
         self._views = []
         if _view_of is not None:
@@ -627,13 +635,42 @@ class Pool:
         self._chk(self._lib.tfhe_hip_pool_batch_gate(self._h, int(gate), _ptr(a), _ptr(bb), _ptr(out), len(a)))
         return out
 
-    def batch_gates_mixed(self, gates, a, b) -> np.ndarray:
+    def batch_gates_mixed(self, gates, a, b, keyswitch: bool = True) -> np.ndarray:
         a, b = self._cts(a), self._cts(b)
         g = np.ascontiguousarray(gates, dtype=np.uint8).reshape(-1)
         if len(g) != len(a) or b.shape != a.shape:
             raise ValueError("gates / operand batches differ in length")
         out = np.empty_like(a)
-        self._chk(self._lib.tfhe_hip_pool_batch_gates_mixed(self._h, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
+        fn = self._lib.tfhe_hip_pool_batch_gates_mixed if keyswitch else self._lib.tfhe_hip_pool_batch_gates_mixed_nks
+        self._chk(fn(self._h, _ptr(g), _ptr(a), _ptr(b), _ptr(out), len(a)))
+        return out
+
+    def batch_tlwe_lincomb(self, ca: int, a, cb: int = 0, b=None, cconst: int = 0) -> np.ndarray:
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if (cb & 0xFFFFFFFF) and (bb is None or bb.shape != a.shape):
+            raise ValueError("second operand missing or of a different shape")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_pool_batch_tlwe_lincomb(
+            self._h, ca & 0xFFFFFFFF, _ptr(a), cb & 0xFFFFFFFF, _ptr(bb), cconst & 0xFFFFFFFF, _ptr(out), len(a)))
+        return out
+
+    def batch_lincomb_bootstrap(self, ca: int, a, cb: int = 0, b=None, cconst: int = 0, testvec=None,
+                                keyswitch: bool = True) -> np.ndarray:
+        a = self._cts(a)
+        bb = self._cts(b) if b is not None else None
+        if (cb & 0xFFFFFFFF) and (bb is None or bb.shape != a.shape):
+            raise ValueError("second operand missing or of a different shape")
+        tv, per_ct = None, 0
+        if testvec is not None:
+            tv = _u32(testvec)
+            per_ct = int(tv.ndim == 3)
+            if tv.size != (len(a) if per_ct else 1) * 2 * N:
+                raise ValueError("test vector must be [2][N], or [count][2][N] for per-ciphertext tables")
+        out = np.empty_like(a)
+        self._chk(self._lib.tfhe_hip_pool_batch_lincomb_bootstrap(
+            self._h, ca & 0xFFFFFFFF, _ptr(a), cb & 0xFFFFFFFF, _ptr(bb), cconst & 0xFFFFFFFF, _ptr(tv), per_ct,
+            int(keyswitch), _ptr(out), len(a)))
         return out
 
     def batch_bootstrap(self, cts, testvec=None, keyswitch: bool = True) -> np.ndarray:
@@ -663,3 +700,112 @@ class Pool:
         out = np.empty((len(cts), 2, N), np.uint32)
         self._chk(self._lib.tfhe_hip_pool_batch_blind_rotate(self._h, _ptr(cts), _ptr(tv), _ptr(out), len(cts)))
         return out
+
+    # -- a batch resident on ONE member's GPU (torch CUDA tensors on member `home`'s device; enqueue only) ----------
+    # Same signatures as Engine's *_dev methods plus `home` (default: self.home), so Circuit.run_dev,
+    # circuit.mux_and_gates_dev and circuit.lut_add_u8_dev take a Pool wherever they take an Engine: shard 0 is
+    # computed in place on the home GPU, the others travel by grouped RCCL send / receive (or peer copies) and come
+    # back in input order (`tfhe_hip_pool_batch_*_dev`, include/tfhe_hip.h).
+    @property
+    def device(self) -> int:
+        return self.devices[self.home]
+
+    def _home(self, home) -> int:
+        h = self.home if home is None else int(home)
+        if not 0 <= h < len(self.devices):
+            raise ValueError("no such pool member")
+        return h
+
+    def _dev_batch(self, home: int, *tensors, width=None) -> int:
+        width = self.params.n + 1 if width is None else width
+        first = tensors[0]
+        for t in tensors:
+            if t is None:
+                continue
+            if t.dim() != 2 or t.shape[1] != width or t.shape[0] != first.shape[0]:
+                raise ValueError(f"device tensors must all be [count][{width}]")
+            if t.device.index != self.devices[home]:
+                raise ValueError(f"device tensor lives on {t.device}, the home member on cuda:{self.devices[home]}")
+        return first.shape[0]
+
+    def _tp(self, home: int, t):
+        p = _tptr(t)
+        if t is not None and t.device.index != self.devices[home]:
+            raise ValueError(f"device tensor lives on {t.device}, the home member on cuda:{self.devices[home]}")
+        return p
+
+    _stream_ptr = staticmethod(Engine._stream_ptr)
+
+    def batch_gate_dev(self, gate: int, a, b, out, stream=None, home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, a, b, out)
+        self._chk(self._lib.tfhe_hip_pool_batch_gate_dev(self._h, h, int(gate), self._tp(h, a), self._tp(h, b), self._tp(h, out),
+                                                         count, self._stream_ptr(stream)))
+
+    def batch_gates_mixed_dev(self, gates, a, b, out, stream=None, keyswitch: bool = True, home=None) -> None:
+        h = self._home(home)
+        if not gates.is_cuda or gates.element_size() != 1 or not gates.is_contiguous() or gates.device.index != self.devices[h]:
+            raise ValueError("gates must be a contiguous uint8 CUDA tensor on the home member's GPU")
+        count = self._dev_batch(h, a, b, out)
+        if gates.numel() != count:
+            raise ValueError("one gate code per ciphertext")
+        fn = self._lib.tfhe_hip_pool_batch_gates_mixed_dev if keyswitch else self._lib.tfhe_hip_pool_batch_gates_mixed_nks_dev
+        self._chk(fn(self._h, h, C.c_void_p(gates.data_ptr()), self._tp(h, a), self._tp(h, b), self._tp(h, out), count,
+                     self._stream_ptr(stream)))
+
+    def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None,
+                            home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, cts, out)
+        if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
+            raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
+        self._chk(self._lib.tfhe_hip_pool_batch_bootstrap_dev(self._h, h, self._tp(h, cts), self._tp(h, testvec), int(per_ct),
+                                                              int(keyswitch), self._tp(h, out), count, self._stream_ptr(stream)))
+
+    def batch_tlwe_lincomb_dev(self, ca: int, a, cb: int, b, cconst: int, out, stream=None, home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, a, b, out)
+        self._chk(self._lib.tfhe_hip_pool_batch_tlwe_lincomb_dev(
+            self._h, h, ca & 0xFFFFFFFF, self._tp(h, a), cb & 0xFFFFFFFF, self._tp(h, b), cconst & 0xFFFFFFFF, self._tp(h, out),
+            count, self._stream_ptr(stream)))
+
+    def batch_lincomb_bootstrap_dev(self, ca: int, a, cb: int, b, cconst: int, out, testvec=None, per_ct: bool = False,
+                                    keyswitch: bool = True, stream=None, home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, a, b, out)
+        if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
+            raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
+        self._chk(self._lib.tfhe_hip_pool_batch_lincomb_bootstrap_dev(
+            self._h, h, ca & 0xFFFFFFFF, self._tp(h, a), cb & 0xFFFFFFFF, self._tp(h, b), cconst & 0xFFFFFFFF,
+            self._tp(h, testvec), int(per_ct), int(keyswitch), self._tp(h, out), count, self._stream_ptr(stream)))
+
+    def batch_mux_dev(self, a, b, c, out, naive: bool, stream=None, home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, a, b, c, out)
+        self._chk(self._lib.tfhe_hip_pool_batch_mux_dev(self._h, h, int(naive), self._tp(h, a), self._tp(h, b), self._tp(h, c),
+                                                        self._tp(h, out), count, self._stream_ptr(stream)))
+
+    def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None, home=None) -> None:
+        h = self._home(home)
+        count = self._dev_batch(h, cts)
+        if out_trlwe.numel() != count * 2 * N or (testvec is not None and testvec.numel() != 2 * N):
+            raise ValueError("out_trlwe must be [count][2][N], testvec [2][N]")
+        self._chk(self._lib.tfhe_hip_pool_batch_blind_rotate_dev(self._h, h, self._tp(h, cts), self._tp(h, testvec),
+                                                                 self._tp(h, out_trlwe), count, self._stream_ptr(stream)))
+
+    def synchronize(self) -> None:
+        """Drain every member's own stream (`tfhe_hip_pool_synchronize`); the home stream is the caller's."""
+        self._chk(self._lib.tfhe_hip_pool_synchronize(self._h))
+
+    @property
+    def data_transport(self) -> str:
+        """"rccl" / "peer-copy" / "none": how the last *_dev call moved its shards."""
+        return self._lib.tfhe_hip_pool_data_transport(self._h).decode()
+
+    def set_profiling(self, enabled: bool) -> None:
+        self._chk(self._lib.tfhe_hip_pool_set_profiling(self._h, int(enabled)))
+
+    def transfer_times(self) -> dict:
+        tt = _capi.PoolTransferTimes()
+        self._chk(self._lib.tfhe_hip_pool_get_transfer_times(self._h, C.byref(tt)))
+        return {k: getattr(tt, k) for k, _ in _capi.PoolTransferTimes._fields_}

@@ -23,6 +23,11 @@ void orc_gen_key_switching_key(uint64_t seed, const orc_params *P, const uint32_
 void orc_tlwe_encrypt_f64(uint64_t seed, double p, double alpha, const uint32_t *key, int dim, uint32_t *out);
 int orc_tlwe_decrypt_bool(const uint32_t *ct, const uint32_t *key, int dim);
 int orc_tlwe_decrypt_lwe_message(const uint32_t *ct, int m, const uint32_t *key, int dim);
+// the four HIP runtime calls the device-resident pool test needs (libamdhip64 is linked; no HIP headers under g++)
+int hipMalloc(void **p, size_t bytes);
+int hipFree(void *p);
+int hipMemcpy(void *dst, const void *src, size_t bytes, int kind);  // 1 = host to device, 2 = device to host
+int hipDeviceSynchronize(void);
 }
 
 using namespace rs_tfhe;
@@ -255,6 +260,71 @@ int main() {
       bool same = one.size() == two.size();
       for (size_t i = 0; same && i < one.size(); ++i) same = one[i].p == two[i].p && tlwe::decrypt_bool(two[i], sk.key_lv0) == want[i];
       CHECK(same, "pool of two contexts equals the single-context batch word for word");
+    }
+    // ... and for a batch that is RESIDENT on one member's GPU (tfhe_hip_pool_batch_*_dev): device pointers in, the
+    // shards travel between the members, device pointer out, input order kept; home = the second member
+    {
+      DevicePool pool(P, {0, 0});
+      pool.load(gk);
+      ChaChaRng r(22);
+      const size_t count = 601, w = (size_t)P.n + 1;
+      gates::Pairs in;
+      for (size_t i = 0; i < count; ++i)
+        in.push_back({tlwe::encrypt_bool((i % 3) == 0, P.alpha_lv0, sk.key_lv0, r), tlwe::encrypt_bool((i & 1) != 0, P.alpha_lv0, sk.key_lv0, r)});
+      std::vector<Torus> fa(count * w), fb(count * w), got(count * w);
+      for (size_t i = 0; i < count; ++i) {
+        std::copy(in[i].first.p.begin(), in[i].first.p.end(), fa.begin() + i * w);
+        std::copy(in[i].second.p.begin(), in[i].second.p.end(), fb.begin() + i * w);
+      }
+      void *da = nullptr, *db = nullptr, *dout = nullptr;
+      const bool alloc = hipMalloc(&da, count * w * 4) == 0 && hipMalloc(&db, count * w * 4) == 0 && hipMalloc(&dout, count * w * 4) == 0;
+      CHECK(alloc, "hipMalloc");
+      if (alloc) {
+        hipMemcpy(da, fa.data(), count * w * 4, 1);
+        hipMemcpy(db, fb.data(), count * w * 4, 1);
+        pool.batch_gate_dev(1, TFHE_HIP_NAND, (const Torus *)da, (const Torus *)db, (Torus *)dout, count);
+        pool.synchronize();
+        hipDeviceSynchronize();
+        hipMemcpy(got.data(), dout, count * w * 4, 2);
+        auto host = pool.batch_gate(TFHE_HIP_NAND, in);
+        bool same = true;
+        for (size_t i = 0; same && i < count; ++i) same = std::equal(host[i].p.begin(), host[i].p.end(), got.begin() + i * w);
+        CHECK(same, "device-resident pool call equals the host-pointer pool call word for word");
+        CHECK(std::string(pool.data_transport()) == "peer-copy", "transport of a pool that repeats a device: %s", pool.data_transport());
+      }
+      hipFree(da);
+      hipFree(db);
+      hipFree(dout);
+    }
+    // tfhe_hip_last_error is per (thread, handle): `Bootstrap: Send + Sync` (bootstrap/mod.rs:23) lets two threads
+    // share one context; the thread that fails must read ITS text while the other keeps working (and sees none)
+    {
+      auto view = Engine::for_key(gk);
+      tfhe_hip_ctx *h = view.handle();
+      ChaChaRng r(23);
+      Ciphertext ca = tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, r);
+      std::atomic<int> bad{0};
+      std::atomic<bool> stop{false};
+      std::thread failing([&] {
+        std::vector<Torus> out(P.n + 1);
+        for (int it = 0; it < 200; ++it) {
+          const int rc = tfhe_hip_batch_gate(h, 99, ca.p.data(), ca.p.data(), out.data(), 1);
+          if (rc != TFHE_HIP_EINVAL || std::string(tfhe_hip_last_error(h)) != "unknown gate") ++bad;
+          const int rc2 = tfhe_hip_batch_sample_extract(h, nullptr, 5000, nullptr, 1);
+          if (rc2 != TFHE_HIP_EINVAL || std::string(tfhe_hip_last_error(h)) != "extraction index out of range") ++bad;
+        }
+      });
+      std::thread working([&] {
+        std::vector<Torus> out(P.n + 1);
+        while (!stop.load()) {
+          if (tfhe_hip_batch_gate(h, TFHE_HIP_NAND, ca.p.data(), ca.p.data(), out.data(), 1) != TFHE_HIP_OK) ++bad;
+          if (std::string(tfhe_hip_last_error(h)) != "") ++bad;  // another thread's failure is not this thread's
+        }
+      });
+      failing.join();
+      stop = true;
+      working.join();
+      CHECK(bad.load() == 0, "per-thread error text: %d mismatches", bad.load());
     }
     // OS-keyed generation (the default): a usable key, different every time
     {

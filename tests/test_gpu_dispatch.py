@@ -1,0 +1,259 @@
+"""GPU tests of the dispatch layer of libtfhe_hip.so: which kernel a batch of a given size runs on must never change the
+result bits.  `tfhe_hip_describe_dispatch` (include/tfhe_hip.h) prints the plan for a count; the tests walk every place
+where the plan changes and hold the default dispatch to ONE fixed pair of kernels (the batch blind rotation + the
+generic key switch, themselves held to the oracle in test_gpu_parity.py) word for word.
+
+Also here: the boundary defects of round 3 (integer atomics into a pinned host output; the kernel attributes of
+contexts created in a different order), the per-thread error text, and the reference's remaining parameter sets
+(SECURITY_UINT6/7/8, src/params.rs:293-376).
+"""
+import re
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import oracle_keys, signed_diff
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+def _cloud_key(ck):
+    from test_gpu_parity import _cloud_key as ck_of
+
+    return ck_of(ck)
+
+
+def _signature(plan: str) -> str:
+    """A plan with its ciphertext ranges removed: 'blind_rotate=batch+single key_switch=mfma(k=4)'."""
+    return re.sub(r"\[\d+,\d+\)", "", plan)
+
+
+@pytest.mark.parametrize("setname,extra", [
+    ("SECURITY_128_BIT", ()),            # l = 3, base 4: pairs, pairs + singles, tails; split -> matrix cores, K chunks 16 ... 1
+    ("SECURITY_UINT1", ()),              # l = 2, base 4, inexact products (bgbit 10 x 2): the kernels must still agree bit for bit
+    ("SECURITY_UINT4", (20481, 33000)),  # l = 1, base 32: split -> column-sliced, K chunks 64 ... 1, accumulator sets 24 ... 40
+])
+def test_dispatch_crossovers_bit_exact(O, monkeypatch, setname, extra):
+    """Every crossover of the automatic dispatch, +-1: the plan is read for every count up to 33 x #CUs (beyond 32 x #CUs
+    the blind rotation is always one batch launch) and each count where it changes is run, with the count before it,
+    through the default dispatch and through the fixed reference pair of kernels on the same random ciphertext words."""
+    import rs_tfhe_amd as R
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    auto = R.Engine(pk.params, 0)
+    auto.load_cloud_key(pk)
+    monkeypatch.setenv("TFHE_HIP_BR_KERNEL", "batch")
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", "generic")
+    fixed = R.Engine(pk.params, 0)
+    fixed.load_cloud_key(pk)
+    monkeypatch.delenv("TFHE_HIP_BR_KERNEL")
+    monkeypatch.delenv("TFHE_HIP_KS_KERNEL")
+    import torch
+
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    limit = 33 * ncu
+    assert _signature(fixed.describe_dispatch(777)) == "blind_rotate=batch key_switch=generic"
+    sigs = [None] + [_signature(auto.describe_dispatch(c)) for c in range(1, limit + 1)]
+    counts = {1, limit}
+    for c in range(2, limit + 1):
+        if sigs[c] != sigs[c - 1]:
+            counts.update((c - 1, c))
+    counts.update(extra)
+    kinds = {s for s in sigs[1:]}
+    # the walk must actually meet every blind-rotation shape and (for the base-4 sets) the matrix cores with 16 ... 1 chunks
+    assert any("pair" in s for s in kinds) and any("batch+single" in s for s in kinds) and any("=single " in s for s in kinds)
+    if op.basebit == 2:
+        assert {f"mfma(k={k})" for k in (16, 8, 4, 2, 1)} <= {s.split("key_switch=")[1] for s in kinds}
+        assert any("split" in s for s in kinds)
+    else:
+        assert any("sliced" in s for s in kinds) and any("split" in s for s in kinds)
+    assert len(counts) < 200, "crossover walk grew unexpectedly"
+    rng = np.random.default_rng(1234)
+    top = max(counts)
+    a = rng.integers(0, 2**32, (top, op.n + 1), dtype=np.uint64).astype(np.uint32)
+    b = rng.integers(0, 2**32, (top, op.n + 1), dtype=np.uint64).astype(np.uint32)
+    ta = torch.from_numpy(a.view(np.int32)).to("cuda:0")
+    tb = torch.from_numpy(b.view(np.int32)).to("cuda:0")
+    seen = set()
+    for c in sorted(counts):
+        seen.add(_signature(auto.describe_dispatch(c)))
+        o1 = torch.empty((c, op.n + 1), dtype=torch.int32, device="cuda:0")
+        o2 = torch.empty_like(o1)
+        auto.batch_gate_dev(O.GATE_NAND, ta[:c], tb[:c], o1)
+        fixed.batch_gate_dev(O.GATE_NAND, ta[:c], tb[:c], o2)
+        auto.synchronize()
+        fixed.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(o1, o2), (setname, c, auto.describe_dispatch(c))
+    if setname == "SECURITY_UINT4":  # the large counts reach the un-chunked column-sliced walk
+        assert any("sliced(k=1," in s for s in seen), seen
+    # and the chain ends at the oracle: a spread sample of the largest default-dispatch batch
+    if setname == "SECURITY_128_BIT":
+        idx = np.linspace(0, top - 1, 40).astype(np.int64)
+        want = O.batch_gate(ck, O.GATE_NAND, a[idx], b[idx])
+        assert np.array_equal(o1.cpu().numpy().view(np.uint32)[idx], want)
+    auto.close()
+    fixed.close()
+
+
+def test_contexts_created_in_any_order_keep_their_lds_limits(O, keys128, keys80):
+    """hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel, not to the context: SECURITY_128 / 110 / 80_BIT
+    share `k_blind_rotate<3, true>` and the latency kernels.  A 128-bit context, THEN an 80-bit one (smaller n, smaller
+    LDS request), then launches on the first again -- batch, single and pair kernels -- must all still run."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    big = R.Engine(pk.params, 0)
+    big.load_cloud_key(pk)
+    sk8, ck8 = keys80
+    pk8 = _cloud_key(ck8)
+    small = R.Engine(pk8.params, 0)
+    small.load_cloud_key(pk8)
+    rng = np.random.default_rng(88)
+    for count in (3, 300, 1500):  # single, pair, batch (+ tail)
+        A, B = rng.integers(0, 2, count).astype(bool), rng.integers(0, 2, count).astype(bool)
+        got8 = small.batch_gate(O.GATE_XOR, sk8.encrypt_bool(A, 881), sk8.encrypt_bool(B, 882))
+        assert np.array_equal(sk8.decrypt_bool(got8), A ^ B)
+        ca, cb = sk.encrypt_bool(A, 883), sk.encrypt_bool(B, 884)
+        got = big.batch_gate(O.GATE_NAND, ca, cb)
+        assert np.array_equal(sk.decrypt_bool(got), ~(A & B)), count
+        idx = np.linspace(0, count - 1, min(count, 12)).astype(np.int64)
+        assert np.array_equal(got[idx], O.batch_gate(ck, O.GATE_NAND, ca[idx], cb[idx]))
+    small.close()
+    big.close()
+
+
+@pytest.mark.parametrize("setname,counts,kernel", [
+    ("SECURITY_128_BIT", (1, 63), "auto"),    # below 64 the base-4 sets take the split kernel (the Gates::nand path of a binding)
+    ("SECURITY_128_BIT", (300,), "split"),    # ... and the same kernel forced at a larger count
+    ("SECURITY_UINT4", (1, 63, 300), "auto"),  # base 32: the split kernel up to 383
+    ("SECURITY_UINT4", (600,), "auto"),       # ... and the column-sliced kernel with K chunks (atomics as well)
+])
+def test_atomic_key_switch_kernels_with_pinned_host_output(O, monkeypatch, setname, counts, kernel):
+    """The split key switch (and every other kernel that merges partial sums with integer atomics) must not aim those
+    atomics at a zero-copy HOST buffer: PCIe AtomicOps are optional for a root complex, and where they are not
+    completed the words come back wrong without any error.  With pinned operands the host entry points run in place;
+    the atomic kernels then go through a device buffer and one copy.  Held to the oracle word for word."""
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd.engine import pinned_copy, pinned_empty
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    if kernel != "auto":
+        monkeypatch.setenv("TFHE_HIP_KS_KERNEL", kernel)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    rng = np.random.default_rng(99)
+    for count in counts:
+        plan = eng.describe_dispatch(count)
+        assert "split" in plan or ("sliced(k=" in plan and "sliced(k=1," not in plan), plan
+        cts = rng.integers(0, 2**32, (count, op.n + 1), dtype=np.uint64).astype(np.uint32)
+        pin, pout = pinned_copy(cts), pinned_empty(cts.shape)
+        pout[...] = 0xDEADBEEF
+        import ctypes as C
+
+        rc = eng._lib.tfhe_hip_batch_bootstrap(eng._ctx, pin.ctypes.data_as(C.c_void_p), None, 0, 1,
+                                               pout.ctypes.data_as(C.c_void_p), count)
+        assert rc == 0, eng._lib.tfhe_hip_last_error(eng._ctx)
+        staged = eng.batch_bootstrap(cts)  # pageable arrays: device staging, the path every other test takes
+        assert np.array_equal(pout, staged), (setname, count)
+        if op.bgbit * op.l <= 20:  # exact products: the oracle's words
+            assert np.array_equal(pout, O.batch_bootstrap(ck, cts)), (setname, count)
+        else:
+            assert signed_diff(sk.phase(pout), sk.phase(O.batch_bootstrap(ck, cts))) < (1 << 26)
+    eng.close()
+
+
+def test_error_text_is_per_thread(O, keys128):
+    """tfhe_hip_last_error under `Send + Sync` use (src/bootstrap/mod.rs:23): a thread that fails reads ITS message,
+    whatever other threads do on the same context meanwhile -- here one thread fails with an unknown gate, one with a
+    NULL operand, a third keeps running correct batches; each failing thread must see its own text every time."""
+    import ctypes as C
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    ca = sk.encrypt_bool(np.array([1, 0, 1], bool), 3131)
+    out = np.empty_like(ca)
+    lib, ctx = eng._lib, eng._ctx
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    bad = []
+    stop = threading.Event()
+
+    def fail_gate():
+        for _ in range(300):
+            rc = lib.tfhe_hip_batch_gate(ctx, 99, p(ca), p(ca), p(out.copy()), 3)
+            msg = lib.tfhe_hip_last_error(ctx).decode()
+            if rc != R._capi.EINVAL or msg != "unknown gate":
+                bad.append(("gate", rc, msg))
+
+    def fail_null():
+        o = np.empty_like(ca)
+        for _ in range(300):
+            rc = lib.tfhe_hip_batch_gate(ctx, 0, p(ca), None, p(o), 3)
+            msg = lib.tfhe_hip_last_error(ctx).decode()
+            if rc != R._capi.EINVAL or msg != "null pointer":
+                bad.append(("null", rc, msg))
+
+    def work():
+        o = np.empty_like(ca)
+        while not stop.is_set():
+            if lib.tfhe_hip_batch_gate(ctx, 0, p(ca), p(ca), p(o), 3) != 0:
+                bad.append(("work", lib.tfhe_hip_last_error(ctx).decode()))
+            elif lib.tfhe_hip_last_error(ctx).decode() != "":
+                bad.append(("work saw another thread's text", lib.tfhe_hip_last_error(ctx).decode()))
+
+    ts = [threading.Thread(target=f) for f in (fail_gate, fail_null, work)]
+    for t in ts:
+        t.start()
+    ts[0].join()
+    ts[1].join()
+    stop.set()
+    ts[2].join()
+    assert not bad, bad[:5]
+    eng.close()
+
+
+@pytest.mark.parametrize("setname,m", [("SECURITY_UINT6", 16), ("SECURITY_UINT7", 16), ("SECURITY_UINT8", 16)])
+def test_pbs_uint6_7_8(O, setname, m):
+    """The reference's three largest parameter sets (src/params.rs:293-376): n = 1071 / 1160, key-switch base 64 / 128
+    (an 0.84 / 1.83 GB key-switching key), through LutBootstrap.  As for SECURITY_UINT5 (test_pbs_other_uint_sets) the
+    ring stays at N = 1024, so the sets are run at message modulus 16; decrypted messages equal f(x) and the CPU
+    path's, phases agree to 1/8 of a message step, and the integer key switch is bit-exact at ragged counts."""
+    import rs_tfhe_amd as R
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    rng = np.random.default_rng(36)
+    msgs = np.concatenate([np.arange(m), rng.integers(0, m, 16)])
+    cts = sk.encrypt_lwe_message(msgs, m, 62)
+    for f in (lambda x: x % m, lambda x: (3 * x + 1) % m):
+        lut = R.lut.Generator(m).generate_lookup_table(f)
+        out = eng.batch_bootstrap(cts, lut.poly)
+        cpu = O.batch_bootstrap(ck, cts, testvec=lut.poly)
+        want = np.array([f(int(x)) for x in msgs])
+        assert np.array_equal(sk.decrypt_lwe_message(cpu, m), want)
+        assert np.array_equal(sk.decrypt_lwe_message(out, m), want)
+        assert signed_diff(sk.phase(out), sk.phase(cpu)) < (1 << 32) // (2 * m) // 8
+    for count in (1, 33, 700):  # split kernel, then whatever the set's batch key switch is
+        lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
+        lv1[0, :N] = 0
+        lv1[-1, :N] = 0xFFFFFFFF
+        got = eng.batch_identity_key_switch(lv1)
+        assert np.array_equal(got, O.batch_identity_key_switching(ck, lv1)), (setname, count, eng.describe_dispatch(count))
+    eng.close()
+    ck.key_switching_key = None  # 0.8 - 1.8 GB each: let the session-wide key cache give them back
+    if hasattr(ck, "_product"):
+        del ck._product

@@ -180,54 +180,70 @@ def test_key_switch_bit_exact(O, eng128, keys128):
         assert np.array_equal(got, exp)
 
 
-@pytest.mark.parametrize("setname,env", [
-    ("SECURITY_128_BIT", {}),                                # default dispatch: LDS ring below 64, matrix cores (K in chunks) from 64
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0"}),         # k_key_switch_b4 (LDS ring, base 4) at every count
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0", "TFHE_HIP_KS_B4": "0"}),  # k_key_switch (generic, buffer loads)
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "0", "TFHE_HIP_KS_SLICED": "2"}),  # k_key_switch_sliced forced at base 4
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<11> (int8 matrix cores), t = 9; K chunks picked per launch (16 ... 4 here)
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "1"}),   # ... the whole walk in one workgroup
-    ("SECURITY_128_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "2"}),   # ... in two
-    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2", "TFHE_HIP_KS_MFMA_KSPLIT": "16"}),   # ... in sixteen, t = 7
-    ("SECURITY_110_BIT", {"TFHE_HIP_KS_MFMA": "2"}),         # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
-    ("SECURITY_80_BIT", {"TFHE_HIP_KS_MFMA": "2"}),          # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
-    ("SECURITY_UINT1", {"TFHE_HIP_KS_MFMA": "2"}),           # k_key_switch_mfma<6>, t = 8
-    ("SECURITY_UINT4", {}),                                  # k_key_switch_sliced (base 32), sets per lane and K chunks picked per launch
-    ("SECURITY_UINT4", {"TFHE_HIP_KS_SL_KCHUNKS": "1"}),     # ... the whole walk in one workgroup (plain stores)
-    ("SECURITY_UINT4", {"TFHE_HIP_KS_SL_KCHUNKS": "64"}),    # ... in 64 chunks of 16 coefficients (= one a_bar stage)
-    ("SECURITY_UINT3", {"TFHE_HIP_KS_SL_KCHUNKS": "8"}),     # base 64 (8-coefficient stages), 8 chunks
-    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "36"}),   # ... forced to 36 sets (what a 65,536 batch picks) / 28 / 40
-    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED_SETS": "28"}),
-    ("SECURITY_UINT2", {"TFHE_HIP_KS_SLICED_SETS": "40"}),
-    ("SECURITY_UINT4", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 32
-    ("SECURITY_UINT2", {}),                                  # base 16
-    ("SECURITY_UINT3", {}),                                  # k_key_switch_sliced, base 64, t = 2
-    ("SECURITY_UINT3", {"TFHE_HIP_KS_SLICED": "0"}),         # k_key_switch (generic) at base 64
+@pytest.mark.parametrize("setname,kernel", [
+    ("SECURITY_128_BIT", "auto"),      # default dispatch: split kernel below 64, matrix cores (K in chunks) from 64
+    ("SECURITY_128_BIT", "b4"),        # k_key_switch_b4 (LDS ring, base 4) at every count
+    ("SECURITY_128_BIT", "generic"),   # k_key_switch (buffer loads)
+    ("SECURITY_128_BIT", "sliced"),    # k_key_switch_sliced forced at base 4
+    ("SECURITY_128_BIT", "mfma"),      # k_key_switch_mfma<11> (int8 matrix cores), t = 9; K chunks picked per launch (16 ... 4 here)
+    ("SECURITY_128_BIT", "split"),     # k_key_switch_split at every count
+    ("SECURITY_110_BIT", "mfma"),      # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
+    ("SECURITY_80_BIT", "mfma"),       # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
+    ("SECURITY_UINT1", "mfma"),        # k_key_switch_mfma<6>, t = 8
+    ("SECURITY_UINT4", "auto"),        # split below 384, k_key_switch_sliced (base 32) from there: sets per lane and K chunks per launch
+    ("SECURITY_UINT4", "sliced"),      # ... at every count (64 / 32 / 16 K chunks at these counts)
+    ("SECURITY_UINT4", "generic"),     # k_key_switch (generic) at base 32
+    ("SECURITY_UINT4", "split"),
+    ("SECURITY_UINT2", "sliced"),      # base 16
+    ("SECURITY_UINT3", "sliced"),      # base 64 (8-coefficient stages), t = 2
+    ("SECURITY_UINT3", "generic"),     # k_key_switch (generic) at base 64
 ])
-def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, env):
-    """Every batch key-switch kernel (the small-batch split kernel switched off), ragged counts that
-    cross the 32- and 512-ciphertext workgroup boundaries, against identity_key_switching
-    (trgsw.rs:332-360) word for word."""
+def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, kernel):
+    """Every key-switch kernel, forced at every batch size with the supported selector TFHE_HIP_KS_KERNEL
+    (include/tfhe_hip.h), at ragged counts that cross the 32-, 128- and 512-ciphertext workgroup boundaries, against
+    identity_key_switching (trgsw.rs:332-360) word for word.  (The per-launch choices -- K chunks, accumulator sets --
+    follow from the count: test_dispatch_crossovers_bit_exact walks them.)"""
     import rs_tfhe_amd as R
 
     op = getattr(O, setname)
     sk, ck = oracle_keys(O, op)
     pk = _cloud_key(ck)
-    monkeypatch.setenv("TFHE_HIP_KS_SPLIT_MAX", "0")
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", kernel)
     eng = R.Engine(pk.params, 0)
     eng.load_cloud_key(pk)
     rng = np.random.default_rng(27)
-    for count in (1, 33, 515) + ((1300,) if "TFHE_HIP_KS_MFMA" in env or "TFHE_HIP_KS_SLICED_SETS" in env else ()):  # several workgroups of rows
+    for count in (1, 33, 515, 1300):  # several workgroups of rows
+        if kernel != "auto":
+            assert f"key_switch={kernel}" in eng.describe_dispatch(count)
         lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
         lv1[0, :N] = 0
         lv1[-1, :N] = 0xFFFFFFFF
         got = eng.batch_identity_key_switch(lv1)
         exp = O.batch_identity_key_switching(ck, lv1) if hasattr(O, "batch_identity_key_switching") else \
             np.stack([O.identity_key_switching(ck, x) for x in lv1])
-        assert np.array_equal(got, exp), (setname, env, count)
+        assert np.array_equal(got, exp), (setname, kernel, count)
     eng.close()
+
+
+def test_kernel_selectors_are_validated(monkeypatch):
+    """TFHE_HIP_BR_KERNEL / TFHE_HIP_KS_KERNEL (the supported controls, include/tfhe_hip.h): unknown values and
+    kernels the parameter set cannot run fail context creation with EINVAL and a message, nothing is allocated."""
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd import _capi
+
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", "mfma")
+    with pytest.raises(_capi.TfheHipError, match="not available"):
+        R.Engine(R.params.SECURITY_UINT4, 0)  # base 32: no matrix-core form
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", "b4")
+    with pytest.raises(_capi.TfheHipError, match="not available"):
+        R.Engine(R.params.SECURITY_UINT4, 0)
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", "nonsense")
+    with pytest.raises(_capi.TfheHipError, match="TFHE_HIP_KS_KERNEL must be"):
+        R.Engine(R.params.SECURITY_128_BIT, 0)
+    monkeypatch.delenv("TFHE_HIP_KS_KERNEL")
+    monkeypatch.setenv("TFHE_HIP_BR_KERNEL", "wide")
+    with pytest.raises(_capi.TfheHipError, match="TFHE_HIP_BR_KERNEL must be"):
+        R.Engine(R.params.SECURITY_128_BIT, 0)
 
 
 def test_blind_rotate_bit_exact(O, eng128, keys128):
@@ -888,29 +904,25 @@ def test_pinned_host_buffers_run_in_place(O, eng128, keys128):
     pool.close()
 
 
-# the four blind-rotation kernels by environment: eight waves per ciphertext (default up to #CUs), one wave per
-# decomposition row (round 1-2), two ciphertexts per eight-wave workgroup (default for #CUs < count <= 2 #CUs; forced
-# at every count here), the batch kernel
+# the three blind-rotation kernels, each forced at every batch size (TFHE_HIP_BR_KERNEL, include/tfhe_hip.h): eight waves
+# per ciphertext (default up to #CUs), two ciphertexts per eight-wave workgroup (default for #CUs < count <= 2 #CUs),
+# the batch kernel
 BR_KERNEL_ENVS = {
-    "wide2": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "1", "TFHE_HIP_PAIR_MAX": "0"},
-    "wide": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "0"},
-    "pair": {"TFHE_HIP_BR_WIDE": "1", "TFHE_HIP_BR_WIDE2": "1", "TFHE_HIP_PAIR_LO": "0", "TFHE_HIP_PAIR_MAX": "1000000"},
-    "batch": {"TFHE_HIP_BR_WIDE": "0"},
+    "single": {"TFHE_HIP_BR_KERNEL": "single"},
+    "pair": {"TFHE_HIP_BR_KERNEL": "pair"},
+    "batch": {"TFHE_HIP_BR_KERNEL": "batch"},
 }
 
 
 def _with_br_kernel(monkeypatch, name):
-    for k in ("TFHE_HIP_BR_WIDE", "TFHE_HIP_BR_WIDE2", "TFHE_HIP_PAIR_LO", "TFHE_HIP_PAIR_MAX"):
-        monkeypatch.delenv(k, raising=False)
     for k, v in BR_KERNEL_ENVS[name].items():
         monkeypatch.setenv(k, v)
 
 
 def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
-    """Small batches go through the latency kernels -- eight waves per ciphertext (blind_rotate_wide.hpp), two
-    ciphertexts per eight-wave workgroup (k_blind_rotate_pair, odd counts included), or the round-2 form with one
-    wave per decomposition row -- larger ones through the one-wave-per-ciphertext batch kernel: all four must give
-    the oracle's bits, for every output form."""
+    """Small batches go through the latency kernels -- eight waves per ciphertext (blind_rotate_wide.hpp) or two
+    ciphertexts per eight-wave workgroup (k_blind_rotate_pair, odd counts included) -- larger ones through the
+    one-wave-per-ciphertext batch kernel: all three must give the oracle's bits, for every output form."""
     import rs_tfhe_amd as R
 
     sk, ck = keys128
@@ -924,17 +936,18 @@ def test_latency_and_batch_kernels_agree(O, keys128, monkeypatch):
         _with_br_kernel(monkeypatch, name)
         eng = R.Engine(pk.params, 0)
         eng.load_cloud_key(pk)
+        assert f"blind_rotate={name}[0,41)" in eng.describe_dispatch(41)
         outs[name] = (eng.batch_gate(O.GATE_NAND, ca, cb), eng.batch_blind_rotate(ca[:5]),
                       eng.batch_bootstrap(ca[:5], keyswitch=False),
                       eng.batch_gates_mixed(np.arange(41, dtype=np.uint8) % 10, ca, cb),
                       eng.batch_gate(O.GATE_XOR, ca[:1], cb[:1]))
         eng.close()
-    for other in ("wide", "pair", "batch"):
-        for x, y in zip(outs["wide2"], outs[other]):
+    for other in ("pair", "batch"):
+        for x, y in zip(outs["single"], outs[other]):
             assert np.array_equal(x, y), other
-    assert np.array_equal(outs["wide2"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
-    assert np.array_equal(outs["wide2"][1], O.batch_blind_rotate(ck, ca[:5]))
-    assert np.array_equal(outs["wide2"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
+    assert np.array_equal(outs["single"][0], O.batch_gate(ck, O.GATE_NAND, ca, cb))
+    assert np.array_equal(outs["single"][1], O.batch_blind_rotate(ck, ca[:5]))
+    assert np.array_equal(outs["single"][2], O.batch_bootstrap(ck, ca[:5], keyswitch=False))
 
 
 def test_pair_kernel_and_tail_launches_in_the_default_dispatch(O, keys128):
@@ -979,11 +992,8 @@ def test_latency_kernels_same_bits_as_batch_kernel_inexact_sets(O, setname, monk
         outs[name] = (eng.batch_blind_rotate(cts[:11]), eng.batch_bootstrap(cts[:11], keyswitch=True))
         eng.close()
     for other in ("pair", "batch"):
-        for x, y in zip(outs["wide2"], outs[other]):
+        for x, y in zip(outs["single"], outs[other]):
             assert np.array_equal(x, y), (setname, other)
-    # The round-1/2 latency kernel (one wave per row) adds ROUNDED partial products instead.  At these widths one LSB of
-    # floating-point noise in a digit moves the mask by a whole (random) key element, so its ciphertexts are different
-    # encryptions of the same phase (the comparison test_pbs_uint4 makes against the oracle): check what they decrypt to.
     for k in outs:  # phases 1/8, 1/4, 3/8 are all in the positive half: the sign test vector gives +1/8 = true
         assert sk.decrypt_bool(outs[k][1]).all(), (setname, k)
 
