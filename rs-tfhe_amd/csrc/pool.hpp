@@ -320,6 +320,10 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   tfhe_hip_ctx *hctx = p->ctxs[(size_t)home];
   tfhe_hip_ctx *hbase = hctx->parent ? hctx->parent : hctx;
   hipStream_t hs = stream_v ? (hipStream_t)stream_v : hbase->stream;
+  // `hs` goes to the member's *_dev entry point as it is (there NULL means "the context's own stream", so the default
+  // stream is named by hipStreamLegacy); the event, wait and RCCL calls below take the runtime's own name for the
+  // default stream, NULL (hipStreamWaitEvent on the hipStreamLegacy handle faults in this HIP runtime)
+  hipStream_t hrt = hs == hipStreamLegacy ? (hipStream_t) nullptr : hs;
   const int world = pool_world_for(p, count);
   std::vector<ncclComm_t> *comms = world > 1 || pool_rccl_mode() >= 2 ? pool_comms(p) : nullptr;
   // TFHE_HIP_POOL_RCCL=2 on a pool of ONE member (plumbing test on a one-GPU box): home's own shard takes the remote
@@ -414,7 +418,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
           const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
           const unsigned char *src = (const unsigned char *)ins[k].ptr + (ins[k].sharded ? sh.lo * ins[k].row_bytes : 0);
           good = hipSetDevice(hctx->device) == hipSuccess &&
-                 R.Send(src, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hs) == ncclSuccess &&
+                 R.Send(src, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hrt) == ncclSuccess &&
                  hipSetDevice(p->ctxs[(size_t)sh.member]->device) == hipSuccess &&
                  R.Recv(st.in[k].p, bytes, ncclUint8, home, (*comms)[(size_t)sh.member], member_stream(sh.member)) == ncclSuccess;
           root->scatter_bytes += bytes;
@@ -433,7 +437,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         if ((e = hipEventCreateWithFlags(&root->ready, hipEventDisableTiming)) != hipSuccess) return hipfail("hipEventCreate", e, home);
         root->ready_device = hctx->device;
       }
-      if ((e = hipEventRecord(root->ready, hs)) != hipSuccess) return hipfail("hipEventRecord", e, home);
+      if ((e = hipEventRecord(root->ready, hrt)) != hipSuccess) return hipfail("hipEventRecord", e, home);
       for (const Sh &sh : shards) {
         if (!sh.remote) continue;
         tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
@@ -479,7 +483,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
     if (comms) {
       if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (gather)");
       bool good = true;
-      timed(root->ev_gather, root->ev_gather_dev, home, hs, true);
+      timed(root->ev_gather, root->ev_gather_dev, home, hrt, true);
       for (const Sh &sh : shards) {
         if (!sh.remote || !good) continue;
         tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
@@ -487,12 +491,12 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         good = hipSetDevice(p->ctxs[(size_t)sh.member]->device) == hipSuccess &&
                R.Send(st.out.p, bytes, ncclUint8, home, (*comms)[(size_t)sh.member], member_stream(sh.member)) == ncclSuccess &&
                hipSetDevice(hctx->device) == hipSuccess &&
-               R.Recv((unsigned char *)out + sh.lo * out_row_bytes, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hs) == ncclSuccess;
+               R.Recv((unsigned char *)out + sh.lo * out_row_bytes, bytes, ncclUint8, sh.member, (*comms)[(size_t)home], hrt) == ncclSuccess;
         root->gather_bytes += bytes;
       }
       good = (R.GroupEnd() == ncclSuccess) && good;
       if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL gather (ncclSend / ncclRecv) failed");
-      timed(root->ev_gather, root->ev_gather_dev, home, hs, false);
+      timed(root->ev_gather, root->ev_gather_dev, home, hrt, false);
     } else {
       for (const Sh &sh : shards) {
         if (!sh.remote) continue;
@@ -512,7 +516,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
       hipError_t e = hipSetDevice(hctx->device);
       if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
       for (const Sh &sh : shards)
-        if (sh.remote && (e = hipStreamWaitEvent(hs, root->stage[(size_t)sh.member].done, 0)) != hipSuccess)
+        if (sh.remote && (e = hipStreamWaitEvent(hrt, root->stage[(size_t)sh.member].done, 0)) != hipSuccess)
           return hipfail("hipStreamWaitEvent", e, home);
     }
   }
