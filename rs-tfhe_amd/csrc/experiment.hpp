@@ -8,7 +8,8 @@
 #pragma once
 #if (defined(TFHE_ABL_NOKEY) && TFHE_ABL_NOKEY) || (defined(TFHE_ABL_NOLDS) && TFHE_ABL_NOLDS) || \
     (defined(TFHE_ABL_NOFFT) && TFHE_ABL_NOFFT) || (defined(TFHE_ABL_TPB_DPP) && TFHE_ABL_TPB_DPP) || \
-    (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER) || (defined(TFHE_ABL_LAT) && TFHE_ABL_LAT)
+    (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER) || (defined(TFHE_ABL_LAT) && TFHE_ABL_LAT) || \
+    (defined(TFHE_ABL_SL) && TFHE_ABL_SL)
 #ifndef TFHE_EXPERIMENT
 #error "TFHE_ABL_* are timing-only experiment switches (results wrong by construction): build with -DTFHE_EXPERIMENT (profiles/exp/build_variants.sh)"
 #endif
@@ -34,4 +35,8 @@
 #endif
 #ifndef TFHE_ABL_KM_NOBARRIER  // matrix-core key switch without its per-step barrier (races: wrong results)
 #define TFHE_ABL_KM_NOBARRIER 0
+#endif
+#ifndef TFHE_ABL_SL  // column-sliced key switch: bit 0 no key DMA, 1 no barrier, 2 (first form only) no a_bar restage after the first,
+                     // 3 no LDS row reads (the additions take registers instead), 4 no additions (rows read and dropped)
+#define TFHE_ABL_SL 0
 #endif

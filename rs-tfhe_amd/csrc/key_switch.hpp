@@ -18,6 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
+#include "experiment.hpp"
+
 namespace tfhe {
 
 __host__ __device__ __forceinline__ int ksk_row_words(int n) { return (n + 1 + 3) & ~3; }
@@ -316,164 +320,274 @@ __global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__rest
   }
 }
 
-// ---- column-sliced variant for wider bases (basebit 3..7: the UINT2..UINT7 sets) ---------------------
-// With base = 32 nearly every ciphertext of a group picks a different candidate row, so k_key_switch
-// fetches a whole 3.3 KB row from L2 for every (ciphertext, group): 662 GB per 65,536-batch at
-// SECURITY_UINT4, L2-bandwidth bound (49 ms).  Here a workgroup owns a SLICE of 64 output columns for
-// 512 ciphertexts: all `base` candidate rows of a group, cut to that slice (base x 256 B), are copied
-// once into an LDS ring by global_load_lds and every ciphertext picks from LDS.  L2 traffic falls by
-// the ciphertexts-per-workgroup ratio (42 GB at UINT4).
-// Lane map: 16 lanes cover the 64 columns (4 each); the 4 lane-quarters of a wave serve 4 different
-// ciphertexts per instruction (ds_read_b128 is serviced in 16-lane groups, so different rows per quarter
-// cost nothing); S accumulator sets per lane -> 4*S ciphertexts per wave, 16*S per workgroup of 4 waves.
-// The digit is per quarter, so the pick is two VALU instructions (v_bfe_u32, v_lshl_add_u32).
-constexpr int kKsSlSets = 32;      // S: accumulator sets per lane (the default; the host picks S per launch, below)
+// ---- column-sliced kernel for wider bases (basebit 4..7: the UINT2..UINT8 sets) ---------------------------------
+// With base = 32 nearly every ciphertext of a group picks a different candidate row, so k_key_switch fetches a whole
+// 3.3 KB row from L2 for every (ciphertext, group): 662 GB per 65,536-batch at SECURITY_UINT4, L2-bandwidth bound
+// (49 ms).  Here a workgroup owns a SLICE of 64 output columns for 16 * S ciphertexts: all `base` candidate rows of a
+// group, cut to that slice (base x 256 B), are copied once into an LDS ring by global_load_lds and every ciphertext
+// picks from LDS.  L2 traffic falls by the ciphertexts-per-workgroup ratio (42 GB at UINT4).
+// Lane map: 16 lanes cover the 64 columns (4 each); the 4 lane-quarters of a wave serve 4 different ciphertexts per
+// instruction (ds_read_b128 is serviced in 16-lane groups, so different rows per quarter cost nothing); S accumulator
+// sets per lane -> 4*S ciphertexts per wave, 16*S per workgroup of 4 waves.
 constexpr int kKsSlWaves = 4;
 __host__ __device__ constexpr int ks_sliced_cts(int sets) { return 4 * sets * kKsSlWaves; }  // ciphertexts per workgroup (512 at S = 32)
-constexpr int kKsSlCts = ks_sliced_cts(kKsSlSets);
-// coefficients whose a_bar words are staged in LDS at a time: 16, or 8 where the ring itself is large
-// (base 64: 3 x 16 KiB), so that two workgroups still share a CU's LDS
-__host__ __device__ __forceinline__ int ks_sliced_stage(int base) { return base >= 64 ? 8 : 16; }
-constexpr int kKsSlSlots = 3;      // ring depth
 
-__host__ __device__ __forceinline__ uint32_t ks_sliced_slot_bytes(int base) {
-  return (uint32_t)((base + 15) & ~15) * 256u;  // whole DMA instructions: 4 rows each, 4 waves
+// The kernel's first form (rounds 1-3: digits extracted per read with v_bfe + v_lshl_add, four v_sub per row read, a_bar
+// words restaged every 16 coefficients behind a drained DMA queue, one barrier per group; 12.4-13.5 ms for 65,536
+// ciphertexts at SECURITY_UINT4) was VALU-issue bound -- profiles/exp/logs/r4_ks_sl_ablation.log: with the key DMA,
+// the barrier, the restage and the LDS reads all removed it still took 7.5 ms.  What follows replaced it (8.2 ms).
+// Pre-digested digits, v_perm picks, v_add3 over pairs of groups:
+//  * the digits are extracted ONCE per (ciphertext, group) by a streaming pre-pass (k_ks_digits) into one byte each,
+//    four groups to a word, laid out [quad of groups][ciphertext]: the kernel DMAs a quad's words for its ciphertexts
+//    straight into LDS (global_load_lds_dword, no registers, no restage stall) one quad ahead;
+//  * the pick is ONE v_perm_b32: LDS address = { 0, 0, digit byte j of the word, lane's column byte } -- the row
+//    stride is 256 B, so the digit byte IS address bits 8..15 -- and the ring slot is the ds_read's immediate offset
+//    (the loop is unrolled over the ring, so slot numbers are compile-time);
+//  * groups are consumed in PAIRS: acc = v_add3_u32(acc, row_g, row_g+1), two VALU instructions per row read where
+//    the first form spends four (the sum is negated once at the end: res = src.b - sum, trgsw.rs:342-356);
+//  * one barrier per pair of groups instead of one per group; the ring holds RP pairs (lookahead RP-1 pairs).
+// VALU per row read: 1 (perm) + 2 (add3) = 3 instead of 6.  Same lane map, same ring layout, same K chunks.
+template <int BASEBIT>
+struct KsSl2 {
+  static constexpr int BASE = 1 << BASEBIT;
+  static constexpr int SLOT = BASE * 256;            // bytes of one group's slice: BASE rows x 64 columns
+  static constexpr int PWG = SLOT / 1024 / kKsSlWaves;  // ring DMA instructions per wave per group (1 KiB each)
+  static_assert(PWG >= 1, "a group's slice must be at least one DMA instruction per wave (base >= 16)");
+};
+__host__ __device__ constexpr int ks_sl2_stage_words(int sets) { return (ks_sliced_cts(sets) + 255) / 256 * 256; }  // per quad, padded to whole DMA rounds
+__host__ __device__ constexpr size_t ks_sl2_lds_bytes(int basebit, int sets, int rp) {
+  return (size_t)2 * rp * ((size_t)(1 << basebit) * 256) + (size_t)2 * ks_sl2_stage_words(sets) * 4;
 }
-__host__ __device__ __forceinline__ size_t ks_sliced_lds_bytes(int base, int sets = kKsSlSets) {
-  return (size_t)kKsSlSlots * ks_sliced_slot_bytes(base) + (size_t)ks_sliced_cts(sets) * ks_sliced_stage(base) * 4;
+// pairs of groups in the ring: 4 (lookahead 6 groups) where two workgroups still share a CU's LDS, else 2
+__host__ __device__ constexpr int ks_sl2_rp(int basebit) { return basebit <= 5 ? 4 : 2; }
+// rows of the digit buffer: the ciphertexts of whole workgroups plus one DMA round of slack
+__host__ __device__ inline size_t ks_sl2_ct_stride(size_t count, int sets) {
+  const size_t cts = (size_t)ks_sliced_cts(sets);
+  return (count + cts - 1) / cts * cts + 256;
 }
-// S is chosen per launch so that the grid fills whole rounds of the machine: a workgroup's time is proportional to
-// S, the grid is ceil(count / 16S) x slices workgroups, `slots` of them run at once, so the launch costs
-// ceil(grid / slots) x S.  At SECURITY_UINT4 (65,536 ciphertexts, 13 slices, 512 slots) S = 32 is 3.25 rounds = 4 x
-// 32; S = 36 is 2.9 rounds = 3 x 36: -16 %.
-__host__ inline int ks_sliced_pick_sets(size_t count, int slices, int slots) {
-  int best = kKsSlSets;
-  size_t best_cost = ~(size_t)0;
-  for (int sets : {24, 28, 32, 36, 40}) {
-    const size_t grid = ((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)) * (size_t)slices;
-    const size_t cost = ((grid + (size_t)slots - 1) / (size_t)slots) * (size_t)sets;
-    if (cost < best_cost || (cost == best_cost && sets == kKsSlSets)) {
-      best = sets;
-      best_cost = cost;
-    }
+
+// The same DMAs with the address split as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit offset in ONE VGPR that
+// never changes): no per-instruction vector address arithmetic, no address registers held across the loop.
+__device__ __forceinline__ void glds16_s(const void *sbase, uint32_t voff, uint32_t lds_dst) {  // 64 lanes x 16 B -> LDS[m0 + 16 * lane]
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ void glds4_s(const void *sbase, uint32_t voff, uint32_t lds_dst) {  // 64 lanes x 4 B -> LDS[m0 + 4 * lane]
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dword %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+// digit pre-pass: lv1 [count][N+1] -> digw [N*t/4][ct_stride] u32, byte b of word (Q, ct) = digit of group 4Q + b
+// (group g = coefficient g / t, level g % t; digit = ((a + prec_offset) >> (32 - (j+1)*basebit)) & (base-1),
+// trgsw.rs:343-349); rows past `count` are all-zero digits (the k = 0 row of every group is zero).
+// One block = 64 ciphertexts x 32 quads: the level-1 words are read along the rows (coalesced), turned in LDS, and
+// the digit words leave ciphertext-major (coalesced).
+__global__ __launch_bounds__(256) void k_ks_digits(const uint32_t *__restrict__ lv1, uint32_t *__restrict__ digw,
+                                                    size_t ct_stride, size_t count, int basebit, int t) {
+  constexpr int N = 1024, QB = 32, CB = 64, WMAX = QB * 4 + 2;  // words of a row a block may need: 128 groups / t (+ ends)
+  __shared__ uint32_t tile[CB][WMAX + 1];
+  const size_t ct0 = (size_t)blockIdx.x * CB;
+  const int q0 = blockIdx.y * QB;           // first quad of this block
+  const int g0 = q0 * 4, g1 = g0 + QB * 4;  // groups [g0, g1)
+  const int i_lo = g0 / t, i_hi = (g1 - 1) / t;  // coefficients needed
+  const int nw = i_hi - i_lo + 1;
+  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+  for (int idx = threadIdx.x; idx < CB * nw; idx += 256) {
+    const int r = idx / nw, w = idx % nw;
+    const size_t ct = ct0 + r;
+    tile[r][w] = ct < count ? lv1[ct * (N + 1) + i_lo + w] + prec_offset : 0u;
   }
-  return best;
+  __syncthreads();
+  const uint32_t mask = (1u << basebit) - 1u;
+  for (int idx = threadIdx.x; idx < CB * QB; idx += 256) {
+    const int r = idx % CB, q = idx / CB;
+    const size_t ct = ct0 + r;
+    uint32_t word = 0;
+    if (ct < count) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int g = g0 + q * 4 + b, i = g / t, j = g - i * t;
+        const uint32_t k = (tile[r][i - i_lo] >> (32 - (j + 1) * basebit)) & mask;
+        word |= k << (8 * b);
+      }
+    }
+    if (ct < ct_stride) digw[(size_t)(q0 + q) * ct_stride + ct] = word;
+  }
 }
 
-template <int IC, int S = kKsSlSets>
-__global__ __launch_bounds__(256) void k_key_switch_sliced(const uint32_t *__restrict__ lv1,  // [count][N+1]
-                                                            const unsigned char *__restrict__ ksk,  // engine layout
-                                                            int n, int basebit, int t,
-                                                            uint32_t *__restrict__ out, size_t count) {
-  // gridDim.z = K chunks: small batches cut the walk over the N coefficients into that many workgroups, which meet
-  // in the (then zeroed) output through integer atomics -- u32 addition commutes: same bits in any arrival order
-  constexpr int N = 1024, NS = kKsSlSlots, D = NS - 1, CTS = ks_sliced_cts(S);
-  const int kchunks = (int)gridDim.z, i_begin = (int)blockIdx.z * (N / kchunks), i_end = i_begin + N / kchunks;
+template <int BASEBIT, int S, int RP>
+__global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__restrict__ digw, size_t ct_stride,
+                                                             const uint32_t *__restrict__ lv1,       // [count][N+1]: the body word
+                                                             const unsigned char *__restrict__ ksk,  // engine layout
+                                                             int n, int t, uint32_t *__restrict__ out, size_t count) {
+  using G = KsSl2<BASEBIT>;
+  constexpr int N = 1024, BASE = G::BASE, SLOT = G::SLOT, PWG = G::PWG, RG = 2 * RP, CTS = ks_sliced_cts(S);
+  constexpr int STW = ks_sl2_stage_words(S);       // stage words per quad (one per ciphertext, padded)
+  constexpr int ST = STW / 64 / kKsSlWaves;        // stage DMA instructions per wave per quad (256 B each)
+  constexpr int PW = 2 * PWG;                      // ring DMA instructions per wave per pair
+  static_assert(RP == 2 || RP == 4, "ring of 2 or 4 pairs");
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
   extern __shared__ __attribute__((aligned(16))) unsigned char sl_smem[];
-  const uint32_t base = 1u << basebit;
-  const uint32_t row_bytes = (uint32_t)ksk_row_words(n) * 4u;
-  const uint32_t slot_bytes = ks_sliced_slot_bytes((int)base);
-  const uint32_t cw = slot_bytes >> 12;  // DMA instructions per wave per group (1 KiB = 4 row slices each)
-  const uint32_t off_ab = NS * slot_bytes;
-  uint32_t(*s_ab)[IC] = reinterpret_cast<uint32_t(*)[IC]>(sl_smem + off_ab);  // [ciphertext][coefficient]
+  constexpr uint32_t off_stage = (uint32_t)RG * SLOT;
   const uint32_t lds_base = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char *)sl_smem;
+  if (lds_base != 0u) __builtin_trap();  // (the row reads below address the ring from 0)
+  const uint32_t row_bytes = (uint32_t)ksk_row_words(n) * 4u;
 
   const int tid = threadIdx.x;
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t lane = (uint32_t)(tid & 63);
   const uint32_t sub = lane >> 4, c4 = lane & 15u;
   const size_t ct0 = (size_t)blockIdx.x * CTS;
-  const uint32_t col0 = blockIdx.y * 64u;  // first column of this slice
-  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
-  const uint32_t total = (uint32_t)N * (uint32_t)t;
-  const uint32_t total_rows = total * base;
+  const uint32_t col0 = blockIdx.y * 64u;
+  const uint32_t total = (uint32_t)N * (uint32_t)t;  // groups
+  const uint32_t kchunks = gridDim.z, gpz = total / kchunks;  // groups of this workgroup: a multiple of RG (host)
+  const uint32_t g_begin = blockIdx.z * gpz, g_end = g_begin + gpz;
 
-  // group q: rows q*base .. q*base+base-1; DMA instruction x of a group moves row slices 4x..4x+3
-  // (lane quarter = row, 16 lanes x 16 B = the 256-byte slice).  Rows past the group (padding up to a
-  // whole instruction) and past the key are clamped to a valid row: they land in LDS rows no digit selects.
-  auto dma_group = [&](uint32_t q) {
-    const uint32_t slot = q % NS;
-    for (uint32_t c = 0; c < cw; ++c) {
+  // group g -> ring slot g % RG; instruction x of a group moves rows 4x .. 4x+3 (lane quarter = row).  Past the range
+  // the source is clamped (the bytes land in slots nobody reads again); every wave issues exactly PWG per group.
+  const uint32_t voff_ring = sub * row_bytes + c4 * 16u;  // this lane's row of the four an instruction moves, its 16 bytes
+  const uint32_t voff_stage = lane * 4u;
+  auto dma_group = [&](uint32_t g) {
+    const uint32_t slot = g % RG;
+    const uint32_t gs = g < total ? g : total - 1u;  // (rows gs * BASE + 4x + sub < total * BASE: always inside the key)
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)PWG; ++c) {
       const uint32_t x = wave + c * kKsSlWaves;
-      uint32_t row = (q < total ? q : total - 1u) * base + 4u * x + sub;
-      row = row < total_rows ? row : total_rows - 1u;
-      const size_t gofs = (size_t)row * row_bytes + col0 * 4u + c4 * 16u;
-      glds16(ksk + gofs, lds_base + slot * slot_bytes + x * 1024u);
+      glds16_s(ksk + (size_t)(gs * BASE + 4u * x) * row_bytes + col0 * 4u, voff_ring, lds_base + slot * SLOT + x * 1024u);
+    }
+  };
+  // quad Q -> stage buffer Q & 1: one word per ciphertext of this workgroup (padded to STW)
+  auto dma_stage = [&](uint32_t Q) {
+    const uint32_t Qs = Q < total / 4u ? Q : total / 4u - 1u;
+#pragma unroll
+    for (uint32_t c = 0; c < (uint32_t)ST; ++c) {
+      const uint32_t y = wave + c * kKsSlWaves;
+      glds4_s(digw + (size_t)Qs * ct_stride + ct0 + y * 64u, voff_stage, lds_base + off_stage + (Q & 1u) * (STW * 4u) + y * 256u);
     }
   };
 
   u32x4 acc[S];
 #pragma unroll
   for (int a = 0; a < S; ++a) acc[a] = u32x4{0u, 0u, 0u, 0u};
+  const uint32_t lane_col = c4 * 16u;  // address byte 0; byte 1 comes from the digit
+  const uint32_t my_ct = wave * (4u * S) + sub;  // + 4a: this lane quarter's ciphertexts within the workgroup
 
-  uint32_t q = (uint32_t)i_begin * (uint32_t)t;
-#pragma unroll 1
-  for (uint32_t d = 0; d < (uint32_t)D; ++d) dma_group(q + d);
-
-#pragma unroll 1
-  for (int i0 = i_begin; i0 < i_end; i0 += IC) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int idx = tid; idx < CTS * IC; idx += 256) {
-      const int c = idx / IC, ii = idx % IC;
-      const size_t ct = ct0 + c;
-      s_ab[c][ii] = ct < count ? lv1[ct * (N + 1) + i0 + ii] + prec_offset : 0u;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int ii = 0; ii < IC; ++ii) {
-      uint32_t ab[S];  // this lane quarter's ciphertexts: wave*4S + 4a + sub
+  // prologue, in the steady-state order [stage][ring]: the first quad's digits, ring pairs 0 .. RP-2
+  dma_stage(g_begin / 4u);
 #pragma unroll
-      for (int a = 0; a < S; ++a) ab[a] = s_ab[wave * (4 * S) + 4 * a + sub][ii];
-#pragma unroll 1
-      for (int j = 0; j < t; ++j, ++q) {
-        // every wave issues exactly cw DMAs per group: this wave's pieces of group q have landed when at
-        // most the D-1 younger groups' are outstanding; the barrier makes all waves' pieces visible and
-        // retires group q-1, whose slot the next DMA refills
-        if (cw == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 1) : "memory");
-        else if (cw == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 2) : "memory");
-        else if (cw == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 4) : "memory");
-        else if (cw == 8) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * 8) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        dma_group(q + (uint32_t)D);
-        const uint32_t sh = 32u - (uint32_t)(j + 1) * (uint32_t)basebit;
-        const uint32_t lane_base = (q % NS) * slot_bytes + c4 * 16u;
-#ifndef TFHE_KS_SL_GB36
-#define TFHE_KS_SL_GB36 6
+  for (uint32_t p = 0; p + 1 < (uint32_t)RP; ++p) {
+    dma_group(g_begin + 2u * p);
+    dma_group(g_begin + 2u * p + 1u);
+  }
+
+  uint32_t abw[S];
+  // one step = one pair of groups; `pc` carries the step's position in the ring as a compile-time constant (slot
+  // offsets, digit byte selectors and the counted waits are immediates)
+  auto step = [&](uint32_t g, auto pc) {
+    constexpr int p = decltype(pc)::value;
+    {
+      // Step: this wave's pieces of the pair (issued RP-1 steps ago) have landed when at most what it issued since is
+      // outstanding: (RP-2) further pairs and the one stage batch that falls into those steps; on a quad's first
+      // step the quad's digits (issued two steps ago, BEFORE that step's pair) must have landed too.
+      if (RP == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (p % 2 == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RP - 2) * PW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RP - 2) * PW + ST) : "memory");
+      if (!(TFHE_ABL_SL & 2)) __builtin_amdgcn_s_barrier();  // every wave's pieces are visible; the pair consumed last step is retired
+      asm volatile("" ::: "memory");
+      const uint32_t quad = (g + 2u * p) / 4u;
+      if (p % 2 == 0) dma_stage(quad + 1u);
+      if (!(TFHE_ABL_SL & 1)) {
+        dma_group(g + 2u * (p + RP - 1));
+        dma_group(g + 2u * (p + RP - 1) + 1u);
+      }
+      if (p % 2 == 0) {  // the quad's digit words of this lane quarter's ciphertexts
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(sl_smem + off_stage + (quad & 1u) * (STW * 4u));
+#pragma unroll
+        for (int a = 0; a < S; ++a) abw[a] = st[my_ct + 4u * a];
+      }
+      constexpr uint32_t slot0 = (uint32_t)((2 * p) % RG) * SLOT, slot1 = (uint32_t)((2 * p + 1) % RG) * SLOT;
+      constexpr uint32_t sel0 = 0x0C0C0400u + ((uint32_t)((2 * p) % 4) << 8), sel1 = 0x0C0C0400u + ((uint32_t)((2 * p + 1) % 4) << 8);
+      // Software pipeline over batches of GB ciphertexts: the picks and row reads of batch b+1 are issued BEFORE the
+      // additions of batch b, so the LDS always has this wave's next reads queued while its VALU adds (with the reads
+      // drained per batch the two pipes took turns: 8.4 ms = VALU 3.8 + LDS 4.6 at SECURITY_UINT4).  The batches are
+      // fenced for the scheduler: hoisting still more reads over additions only costs registers.
+#ifndef TFHE_KS_SL2_GB
+#define TFHE_KS_SL2_GB 2
 #endif
-        // LDS reads in flight per lane before their subtractions; divides S (24 .. 40 in steps of 4)
-        constexpr int GB = S % 8 == 0 ? 8 : (S == 36 ? TFHE_KS_SL_GB36 : 4);
-        static_assert(S % GB == 0, "the read group must divide S");
+      constexpr int GB = TFHE_KS_SL2_GB, NB = S / GB;
+      static_assert(S % GB == 0, "the read batch must divide S");
+      u32x4 r0[2][GB], r1[2][GB];
+      auto issue = [&](int bt, int buf) {
 #pragma unroll
-        for (int gb = 0; gb < S; gb += GB) {
-          u32x4 v[GB];
-#pragma unroll
-          for (int g = 0; g < GB; ++g) {
-            const uint32_t k = __builtin_amdgcn_ubfe(ab[gb + g], sh, (uint32_t)basebit);
-            v[g] = *reinterpret_cast<const u32x4 *>(sl_smem + ((k << 8) + lane_base));
+        for (int x = 0; x < GB; ++x) {
+          const uint32_t a0 = __builtin_amdgcn_perm(abw[bt * GB + x], lane_col, sel0);
+          const uint32_t a1 = __builtin_amdgcn_perm(abw[bt * GB + x], lane_col, sel1);
+          // LDS addresses as integers: the dynamic LDS of a kernel without static LDS starts at 0 (checked on entry), so
+          // the picked address goes to the ds_read as it is and the slot rides in the instruction's offset field
+          if (TFHE_ABL_SL & 8) {  // timing-only: no LDS row reads
+            r0[buf][x] = u32x4{a0, a1, a0 ^ a1, a0 + 1u};
+            r1[buf][x] = u32x4{a1, a0, a1 + 1u, a0 & a1};
+            continue;
           }
+          r0[buf][x] = *(const __attribute__((address_space(3))) u32x4 *)(uintptr_t)(a0 + slot0);
+          r1[buf][x] = *(const __attribute__((address_space(3))) u32x4 *)(uintptr_t)(a1 + slot1);
+        }
+      };
+      issue(0, 0);
 #pragma unroll
-          for (int g = 0; g < GB; ++g) acc[gb + g] -= v[g];
+      for (int bt = 0; bt < NB; ++bt) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (bt + 1 < NB) issue(bt + 1, (bt + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < GB; ++x) {
+          if (TFHE_ABL_SL & 16) {  // timing-only: the rows are read and dropped
+            asm volatile("" ::"v"(r0[bt & 1][x]), "v"(r1[bt & 1][x]));
+            continue;
+          }
+          acc[bt * GB + x] += r0[bt & 1][x] + r1[bt & 1][x];  // v_add3_u32 x 4
         }
       }
     }
+  };
+#pragma unroll 1
+  for (uint32_t g = g_begin; g < g_end; g += RG) {  // one ring's worth of groups: RP steps
+    step(g, std::integral_constant<int, 0>{});
+    step(g, std::integral_constant<int, 1>{});
+    if constexpr (RP == 4) {
+      step(g, std::integral_constant<int, 2>{});
+      step(g, std::integral_constant<int, 3>{});
+    }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // trailing (clamped) DMAs before the LDS goes away
 #pragma unroll
   for (int a = 0; a < S; ++a) {
-    const size_t ct = ct0 + wave * (4 * S) + 4 * a + sub;
+    const size_t ct = ct0 + my_ct + 4u * a;
     if (ct < count) {
       uint32_t *o = out + ct * (size_t)(n + 1);
-      const uint32_t w[4] = {acc[a].x, acc[a].y, acc[a].z, acc[a].w};
+      const uint32_t w[4] = {0u - acc[a].x, 0u - acc[a].y, 0u - acc[a].z, 0u - acc[a].w};  // res = src.b - sum
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int x = (int)(col0 + c4 * 4u) + c;
         if (kchunks == 1) {
           if (x < n) o[x] = w[c];
-          if (x == n) o[x] = w[c] + lv1[ct * (N + 1) + N];  // res.b = src.b - sum (trgsw.rs:342)
+          if (x == n) o[x] = w[c] + lv1[ct * (N + 1) + N];  // trgsw.rs:342
         } else if (x <= n) {
           const uint32_t v = w[c] + ((x == n && blockIdx.z == 0) ? lv1[ct * (N + 1) + N] : 0u);
           if (v) atomicAdd(&o[x], v);

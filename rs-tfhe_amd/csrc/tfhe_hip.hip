@@ -81,7 +81,7 @@ struct tfhe_hip_ctx {
   int views = 0;                 // live key views of this context
   bool dying = false;            // destroyed while views were alive: the last view to go frees the context
   double2 *d_tw = nullptr;
-  DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out;  // scratch / host-API staging
+  DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out, ks_dig;  // scratch / host-API staging (ks_dig: key-switch digit bytes)
   PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
   bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
   std::mutex mu;
@@ -101,7 +101,7 @@ struct tfhe_hip_ctx {
   size_t ks_split_max = 256;  // key switch: coefficient walk split over 32 workgroups up to this batch size
   size_t ks_mfma_min = 64;    // smallest batch the matrix-core kernel takes (below: the split kernel)
   size_t ks_sl_chunk_min = 384;  // wider bases: smallest batch the column-sliced kernel takes (with K chunks; below: the split kernel)
-  int ks_sliced_sets = 0;     // 0: accumulator sets per lane picked per launch (ks_sliced_pick_sets); else forced (24..40)
+  int ks_sliced_sets = 0;     // 0: accumulator sets per lane picked per launch (ks_sl2_pick_sets); else forced (24..36; experiment builds)
   int ks_mfma_ksplit = 0;     // 0: K chunks per row block picked per launch; else forced (1, 2, 4, 8, 16)
   int ks_sl_kchunks = 0;      // 0: K chunks of the column-sliced kernel picked per launch; else forced (1 ... 64, a power of two)
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
@@ -470,7 +470,55 @@ struct KsPlan {
   bool atomics = false;
 };
 
-bool ks_sliced_fits(const tfhe_hip_params &P) { return ks_sliced_lds_bytes(1 << P.basebit) <= 64 * 1024; }
+// column-sliced kernel (second form): bases 16 .. 128, its ring + stage within a CU's LDS
+bool ks_sliced_fits(const tfhe_hip_params &P) {
+  return P.basebit >= 4 && P.basebit <= 7 && ks_sl2_lds_bytes(P.basebit, 36, ks_sl2_rp(P.basebit)) <= 160 * 1024;
+}
+constexpr size_t kKsSl2Slab = 131072;  // ciphertexts per launch of the column-sliced kernel (bounds its digit scratch: 0.4 GB at t = 3)
+typedef void (*sl2_kernel_t)(const uint32_t *, size_t, const uint32_t *, const unsigned char *, int, int, uint32_t *, size_t);
+template <int BB>
+sl2_kernel_t sl2_kernel_sets(int sets) {
+  constexpr int RP = ks_sl2_rp(BB);
+  switch (sets) {
+    case 24: return k_key_switch_sliced<BB, 24, RP>;
+    case 28: return k_key_switch_sliced<BB, 28, RP>;
+    case 36: return k_key_switch_sliced<BB, 36, RP>;
+    default: return k_key_switch_sliced<BB, 32, RP>;
+  }
+}
+sl2_kernel_t sl2_kernel(int basebit, int sets) {
+  switch (basebit) {
+    case 4: return sl2_kernel_sets<4>(sets);
+    case 5: return sl2_kernel_sets<5>(sets);
+    case 6: return sl2_kernel_sets<6>(sets);
+    default: return sl2_kernel_sets<7>(sets);
+  }
+}
+// Accumulator sets per lane, chosen per launch so that the grid fills whole rounds of the machine: a workgroup's time is
+// proportional to S, the grid is ceil(count / 16S) x slices workgroups, `slots` of them run at once, so the launch
+// costs ceil(grid / slots) x S (SECURITY_UINT4, 65,536 ciphertexts, 13 slices, 512 slots: S = 32 is 3.25 rounds = 4 x 32,
+// S = 36 is 2.9 rounds = 3 x 36).  Base 64 keeps to the sets whose code does not spill (28: 7.0 ms, 36: 8.1 at
+// SECURITY_UINT3); base 128 (one workgroup per CU) runs best at 36 (26.5 ms vs 28.6 / 31.0 at 32 / 28, SECURITY_UINT7) --
+// profiles/exp/logs/r4_ks_sl_ablation.log.
+bool ks_sl2_sets_allowed(int basebit, int sets) {
+  if (basebit == 6) return sets == 24 || sets == 28;
+  if (basebit == 7) return sets == 36;
+  return sets == 24 || sets == 28 || sets == 32 || sets == 36;
+}
+int ks_sl2_pick_sets(int basebit, size_t count, int slices, int slots) {
+  int best = basebit == 7 ? 36 : basebit == 6 ? 28 : 32;
+  size_t best_cost = ~(size_t)0;
+  for (int sets : {24, 28, 32, 36}) {
+    if (!ks_sl2_sets_allowed(basebit, sets)) continue;
+    const size_t grid = ((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)) * (size_t)slices;
+    const size_t cost = ((grid + (size_t)slots - 1) / (size_t)slots) * (size_t)sets;
+    if (cost < best_cost || (cost == best_cost && sets == 32)) {
+      best = sets;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
 bool ks_b4_fits(const tfhe_hip_params &P) {
   const int bd = ((ksk_row_words(P.n) >> 2) + 63) & ~63;
   return P.basebit == 2 && ks_b4_lds_bytes(bd >> 6, kKsG) <= 64 * 1024;
@@ -500,7 +548,7 @@ KsPlan plan_key_switch(const tfhe_hip_ctx *ctx, size_t count) {
   if (forced) pl.kind = (KsKind)(ctx->ks_force - 1);
   else if (ctx->K->d_ksk8 && count >= ctx->ks_mfma_min) pl.kind = KS_MFMA;
   else {
-    const bool sliced_ok = P.basebit != 2 && ks_sliced_fits(P);
+    const bool sliced_ok = ks_sliced_fits(P);
     if (count <= ctx->ks_split_max && !(sliced_ok && count >= ctx->ks_sl_chunk_min)) pl.kind = KS_SPLIT;
     else if (sliced_ok) pl.kind = KS_SLICED;
     else if (ks_b4_fits(P)) pl.kind = KS_B4;
@@ -518,17 +566,21 @@ KsPlan plan_key_switch(const tfhe_hip_ctx *ctx, size_t count) {
     pl.kparts = ksplit;
     pl.atomics = true;
   } else if (pl.kind == KS_SLICED) {
-    // accumulator sets per lane: whichever fills whole rounds of the machine (two workgroups per CU)
-    const int slices = (n + 1 + 63) / 64, base = 1 << P.basebit;
-    int sets = ks_sliced_pick_sets(count, slices, 2 * ctx->num_cus);
+    // accumulator sets per lane: whichever fills whole rounds of the machine (workgroups resident at once: two per CU
+    // while two rings fit a CU's LDS, else one)
+    const int slices = (n + 1 + 63) / 64, rp = ks_sl2_rp(P.basebit);
+    const size_t in_launch = count < kKsSl2Slab ? count : kKsSl2Slab;
+    const int per_cu = 2 * ks_sl2_lds_bytes(P.basebit, 36, rp) <= 160 * 1024 ? 2 : 1;
+    int sets = ks_sl2_pick_sets(P.basebit, in_launch, slices, per_cu * ctx->num_cus);
     if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
-    if (ks_sliced_lds_bytes(base, sets) > 64 * 1024) sets = kKsSlSets;
-    // small batches have few ciphertext groups: the walk over the N coefficients is cut into up to 64 chunks (grid.z)
-    // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics
-    const size_t groups = (count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
+    // small batches have few ciphertext groups: the walk over the N * t groups is cut into up to 64 chunks (grid.z)
+    // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics.
+    // A chunk is whole rings (2 * rp groups).
+    const size_t groups = (in_launch + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
     int kchunks = 1;
     while (kchunks < 64 && groups * (size_t)slices * (size_t)kchunks < 2 * (size_t)ctx->num_cus) kchunks *= 2;
     if (ctx->ks_sl_kchunks) kchunks = ctx->ks_sl_kchunks;
+    while (kchunks > 1 && (kN * P.t / kchunks) % (2 * rp) != 0) kchunks /= 2;
     pl.sets = sets;
     pl.kparts = kchunks;
     pl.atomics = kchunks > 1;
@@ -578,6 +630,10 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
       dst = (uint32_t *)ctx->ks_out.p;
     }
   }
+  if (pl.kind == KS_SLICED) {
+    const size_t in_launch = count < kKsSl2Slab ? count : kKsSl2Slab;
+    CHK(ensure(ctx, ctx->ks_dig, (size_t)(kN * P.t / 4) * ks_sl2_ct_stride(in_launch, pl.sets) * 4));
+  }
   const int rw4 = ksk_row_words(n) >> 2;
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
   const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(n) * 4;
@@ -601,21 +657,23 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
                            (const uint4 *)ctx->K->d_ksk, (uint32_t)ksk_bytes, n, P.basebit, P.t, dst);
         break;
       case KS_SLICED: {
-        const int slices = (n + 1 + 63) / 64, base = 1 << P.basebit;
-        const size_t groups = (count + (size_t)ks_sliced_cts(pl.sets) - 1) / (size_t)ks_sliced_cts(pl.sets);
-        typedef void (*sl_kernel_t)(const uint32_t *, const unsigned char *, int, int, int, uint32_t *, size_t);
-        sl_kernel_t kern = nullptr;
-        const bool ic8 = ks_sliced_stage(base) == 8;
-        switch (pl.sets) {
-          case 24: kern = ic8 ? k_key_switch_sliced<8, 24> : k_key_switch_sliced<16, 24>; break;
-          case 28: kern = ic8 ? k_key_switch_sliced<8, 28> : k_key_switch_sliced<16, 28>; break;
-          case 36: kern = ic8 ? k_key_switch_sliced<8, 36> : k_key_switch_sliced<16, 36>; break;
-          case 40: kern = ic8 ? k_key_switch_sliced<8, 40> : k_key_switch_sliced<16, 40>; break;
-          default: kern = ic8 ? k_key_switch_sliced<8, 32> : k_key_switch_sliced<16, 32>; break;
+        // digits first (k_ks_digits: one byte per (ciphertext, group), [quad of groups][ciphertext]), then the walk;
+        // slabs of kKsSl2Slab ciphertexts bound the digit scratch
+        const int slices = (n + 1 + 63) / 64, rp = ks_sl2_rp(P.basebit);
+        const size_t lds = ks_sl2_lds_bytes(P.basebit, pl.sets, rp);
+        const sl2_kernel_t kern = sl2_kernel(P.basebit, pl.sets);
+        const unsigned quads = (unsigned)(kN * P.t / 4);
+        for (size_t done = 0; done < count; done += kKsSl2Slab) {
+          const size_t m = count - done < kKsSl2Slab ? count - done : kKsSl2Slab;
+          const size_t ct_stride = ks_sl2_ct_stride(m, pl.sets);
+          const uint32_t *src = lv1 + done * (size_t)(kN + 1);
+          hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)((ct_stride + 63) / 64), quads / 32), dim3(256), 0, s, src,
+                             (uint32_t *)ctx->ks_dig.p, ct_stride, m, P.basebit, P.t);
+          const size_t groups = (m + (size_t)ks_sliced_cts(pl.sets) - 1) / (size_t)ks_sliced_cts(pl.sets);
+          hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices, (unsigned)pl.kparts), dim3(256), lds, s,
+                             (const uint32_t *)ctx->ks_dig.p, ct_stride, src, (const unsigned char *)ctx->K->d_ksk, n, P.t,
+                             dst + done * (size_t)(n + 1), m);
         }
-        hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices, (unsigned)pl.kparts), dim3(256),
-                           ks_sliced_lds_bytes(base, pl.sets), s, lv1, (const unsigned char *)ctx->K->d_ksk, n, P.basebit,
-                           P.t, dst, count);
         break;
       }
       case KS_B4:
@@ -933,7 +991,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_FAST_ROUND")) ctx->fast_round = ctx->fast_round && atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_KS_SLICED_SETS")) {
     const int v = atoi(env);
-    ctx->ks_sliced_sets = (v == 24 || v == 28 || v == 32 || v == 36 || v == 40) ? v : 0;
+    ctx->ks_sliced_sets = (v == 24 || v == 28 || v == 32 || v == 36) ? v : 0;
   }
   if (const char *env = getenv("TFHE_HIP_KS_MFMA_MIN")) ctx->ks_mfma_min = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SL_CHUNK_MIN")) ctx->ks_sl_chunk_min = (size_t)atol(env);
@@ -970,6 +1028,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
       return bail("hipFuncSetAttribute(k_blind_rotate_wide2)", e);
     if (ctx->pair_max && (e = set_lds((const void *)br_pair_kernel(ctx), blind_rotate_pair_lds_bytes(kMaxN))) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate_pair)", e);
+    if (ks_sliced_fits(*p))
+      for (int sets : {24, 28, 32, 36})
+        if ((e = set_lds((const void *)sl2_kernel(p->basebit, sets), ks_sl2_lds_bytes(p->basebit, sets, ks_sl2_rp(p->basebit)))) != hipSuccess)
+          return bail("hipFuncSetAttribute(k_key_switch_sliced)", e);
     if (ks_mfma_possible(*p)) {  // one instantiation per tile count: its LDS size does not depend on n beyond that
       const int nt = ks_mfma_nt(p->n);
       if ((e = set_lds((const void *)km_kernel(nt), ks_mfma_lds_bytes(nt))) != hipSuccess)
@@ -1044,7 +1106,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     (void)hipEventDestroy(p.first);
     (void)hipEventDestroy(p.second);
   }
-  DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx, &ctx->ks_out};
+  DevBuf *bufs[] = {&ctx->lv1, &ctx->u1, &ctx->u2, &ctx->h_a, &ctx->h_b, &ctx->h_c, &ctx->h_out, &ctx->h_tv, &ctx->h_idx, &ctx->ks_out, &ctx->ks_dig};
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   free_key(ctx->own);

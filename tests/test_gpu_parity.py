@@ -184,18 +184,18 @@ def test_key_switch_bit_exact(O, eng128, keys128):
     ("SECURITY_128_BIT", "auto"),      # default dispatch: split kernel below 64, matrix cores (K in chunks) from 64
     ("SECURITY_128_BIT", "b4"),        # k_key_switch_b4 (LDS ring, base 4) at every count
     ("SECURITY_128_BIT", "generic"),   # k_key_switch (buffer loads)
-    ("SECURITY_128_BIT", "sliced"),    # k_key_switch_sliced forced at base 4
     ("SECURITY_128_BIT", "mfma"),      # k_key_switch_mfma<11> (int8 matrix cores), t = 9; K chunks picked per launch (16 ... 4 here)
     ("SECURITY_128_BIT", "split"),     # k_key_switch_split at every count
     ("SECURITY_110_BIT", "mfma"),      # k_key_switch_mfma<5>, t = 8, 5,5,5,5 tiles
     ("SECURITY_80_BIT", "mfma"),       # k_key_switch_mfma<5>, t = 7, 5,5,4,4 tiles
     ("SECURITY_UINT1", "mfma"),        # k_key_switch_mfma<6>, t = 8
-    ("SECURITY_UINT4", "auto"),        # split below 384, k_key_switch_sliced (base 32) from there: sets per lane and K chunks per launch
+    ("SECURITY_UINT4", "auto"),        # split below 384, k_key_switch_sliced2 (base 32) from there: sets per lane and K chunks per launch
     ("SECURITY_UINT4", "sliced"),      # ... at every count (64 / 32 / 16 K chunks at these counts)
     ("SECURITY_UINT4", "generic"),     # k_key_switch (generic) at base 32
     ("SECURITY_UINT4", "split"),
     ("SECURITY_UINT2", "sliced"),      # base 16
-    ("SECURITY_UINT3", "sliced"),      # base 64 (8-coefficient stages), t = 2
+    ("SECURITY_UINT3", "sliced"),      # base 64 (ring of two pairs), t = 2
+    ("SECURITY_UINT7", "sliced"),      # base 128 (one workgroup per CU), n = 1160
     ("SECURITY_UINT3", "generic"),     # k_key_switch (generic) at base 64
 ])
 def test_key_switch_batch_kernels_bit_exact(O, monkeypatch, setname, kernel):
