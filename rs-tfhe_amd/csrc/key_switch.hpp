@@ -359,7 +359,10 @@ __host__ __device__ constexpr size_t ks_sl2_lds_bytes(int basebit, int sets, int
   return (size_t)2 * rp * ((size_t)(1 << basebit) * 256) + (size_t)2 * ks_sl2_stage_words(sets) * 4;
 }
 // pairs of groups in the ring: 4 (lookahead 6 groups) where two workgroups still share a CU's LDS, else 2
-__host__ __device__ constexpr int ks_sl2_rp(int basebit) { return basebit <= 5 ? 4 : 2; }
+#ifndef TFHE_KS_SL2_RP_SMALL  // (experiment knob)
+#define TFHE_KS_SL2_RP_SMALL 4
+#endif
+__host__ __device__ constexpr int ks_sl2_rp(int basebit) { return basebit <= 5 ? TFHE_KS_SL2_RP_SMALL : 2; }
 // rows of the digit buffer: the ciphertexts of whole workgroups plus one DMA round of slack
 __host__ __device__ inline size_t ks_sl2_ct_stride(size_t count, int sets) {
   const size_t cts = (size_t)ks_sliced_cts(sets);
@@ -431,6 +434,10 @@ __global__ __launch_bounds__(256) void k_ks_digits(const uint32_t *__restrict__ 
   }
 }
 
+__device__ __forceinline__ void add3_inplace(uint32_t &acc, uint32_t a, uint32_t b) {
+  asm("v_add3_u32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+
 template <int BASEBIT, int S, int RP>
 __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__restrict__ digw, size_t ct_stride,
                                                              const uint32_t *__restrict__ lv1,       // [count][N+1]: the body word
@@ -482,9 +489,9 @@ __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__
     }
   };
 
-  u32x4 acc[S];
+  uint32_t acc[S][4];
 #pragma unroll
-  for (int a = 0; a < S; ++a) acc[a] = u32x4{0u, 0u, 0u, 0u};
+  for (int a = 0; a < S; ++a) acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0u;
   const uint32_t lane_col = c4 * 16u;  // address byte 0; byte 1 comes from the digit
   const uint32_t my_ct = wave * (4u * S) + sub;  // + 4a: this lane quarter's ciphertexts within the workgroup
 
@@ -561,7 +568,12 @@ __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__
             asm volatile("" ::"v"(r0[bt & 1][x]), "v"(r1[bt & 1][x]));
             continue;
           }
-          acc[bt * GB + x] += r0[bt & 1][x] + r1[bt & 1][x];  // v_add3_u32 x 4
+          // v_add3_u32 x 4, IN PLACE (inline asm: left to itself the allocator rotates the accumulators through the
+          // row buffers' registers across the unrolled steps and needs ~60 more of them; S = 32 / 36 then spill)
+          add3_inplace(acc[bt * GB + x][0], r0[bt & 1][x].x, r1[bt & 1][x].x);
+          add3_inplace(acc[bt * GB + x][1], r0[bt & 1][x].y, r1[bt & 1][x].y);
+          add3_inplace(acc[bt * GB + x][2], r0[bt & 1][x].z, r1[bt & 1][x].z);
+          add3_inplace(acc[bt * GB + x][3], r0[bt & 1][x].w, r1[bt & 1][x].w);
         }
       }
     }
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__
     const size_t ct = ct0 + my_ct + 4u * a;
     if (ct < count) {
       uint32_t *o = out + ct * (size_t)(n + 1);
-      const uint32_t w[4] = {0u - acc[a].x, 0u - acc[a].y, 0u - acc[a].z, 0u - acc[a].w};  // res = src.b - sum
+      const uint32_t w[4] = {0u - acc[a][0], 0u - acc[a][1], 0u - acc[a][2], 0u - acc[a][3]};  // res = src.b - sum
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int x = (int)(col0 + c4 * 4u) + c;
