@@ -24,6 +24,9 @@
 
 #include "blind_rotate.hpp"
 #include "blind_rotate_wide.hpp"
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)
+#include "../../profiles/exp/blind_rotate_l1.hpp"
+#endif
 #if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)
 #include "../../profiles/exp/blind_rotate_wide1.hpp"
 #endif
@@ -233,8 +236,18 @@ int record_end(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_
 }
 
 typedef void (*br_kernel_t)(BlindRotateArgs);
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)  // the three-waves-per-SIMD l = 1 experiment (profiles/exp/blind_rotate_l1.hpp)
+bool br_is_l1(const tfhe_hip_ctx *ctx) { return ctx->P.l == 1; }
+int br_waves(const tfhe_hip_ctx *ctx) { return br_is_l1(ctx) ? kL1Waves : kBrWaves; }
+#else
+constexpr bool br_is_l1(const tfhe_hip_ctx *) { return false; }
+constexpr int br_waves(const tfhe_hip_ctx *) { return kBrWaves; }
+#endif
 br_kernel_t br_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)
+  if (br_is_l1(ctx)) return f ? k_blind_rotate_l1<true> : k_blind_rotate_l1<false>;
+#endif
   switch (ctx->P.l) {
     case 1: return f ? k_blind_rotate<1, true> : k_blind_rotate<1, false>;
     case 2: return f ? k_blind_rotate<2, true> : k_blind_rotate<2, false>;
@@ -278,7 +291,12 @@ ep_kernel_t ep_kernel(const tfhe_hip_ctx *ctx) {
   }
 }
 
-size_t br_lds_bytes(const tfhe_hip_ctx *ctx) { return blind_rotate_lds_bytes(ctx->P.n); }
+size_t br_lds_bytes(const tfhe_hip_ctx *ctx) {
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)
+  if (br_is_l1(ctx)) return blind_rotate_l1_lds_bytes();
+#endif
+  return blind_rotate_lds_bytes(ctx->P.n);
+}
 
 // ---- which blind-rotation kernels a batch of `count` runs on ----------------------------------------
 // Three kernels, one arithmetic (the same per-element operations in the same order: results are the same bits
@@ -420,13 +438,14 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
       if (ctx->br_chunk > 0) chunk = (size_t)ctx->br_chunk;
       if (ctx->br_chunk < 0) {
         int per_cu = 0;
-        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * kBrWaves, lds);
-        if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * kBrWaves;
+        const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * br_waves(ctx), lds);
+        if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * br_waves(ctx);
       }
       if (chunk == 0 || chunk > m_all) chunk = m_all;
       for (size_t done = 0; done < m_all; done += chunk) {
         const size_t m = (m_all - done < chunk) ? m_all - done : chunk;
-        CHK(launch(br_kernel(ctx), (unsigned)((m + kBrWaves - 1) / kBrWaves), 64u * kBrWaves, lds, part(begin + done, m)));
+        const unsigned bw = (unsigned)br_waves(ctx);
+        CHK(launch(br_kernel(ctx), (unsigned)((m + bw - 1) / bw), 64u * bw, lds, part(begin + done, m)));
       }
     }
   }
@@ -1022,7 +1041,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
       const size_t cap = 160 * 1024;
       return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes < cap ? bytes : cap));
     };
-    if ((e = set_lds((const void *)br_kernel(ctx), blind_rotate_lds_bytes(kMaxN))) != hipSuccess)
+    if ((e = set_lds((const void *)br_kernel(ctx), br_is_l1(ctx) ? br_lds_bytes(ctx) : blind_rotate_lds_bytes(kMaxN))) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate)", e);
     if ((e = set_lds((const void *)br_single_kernel(ctx), blind_rotate_wide2_lds_bytes(kMaxN, p->l))) != hipSuccess)
       return bail("hipFuncSetAttribute(k_blind_rotate_wide2)", e);
