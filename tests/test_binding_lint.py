@@ -1,5 +1,5 @@
-"""The Rust binding in INTEGRATION.md cannot be compiled in this image (no rustc): at least hold its `extern "C"`
-block to the header it binds.  Every function it declares must exist in include/tfhe_hip.h with the same number of
+"""The Rust binding under rust/ cannot be compiled in this image (no rustc): at least hold its `extern "C"`
+blocks to the header they bind.  Every function it declares must exist in include/tfhe_hip.h with the same number of
 parameters and the same shape per parameter (pointer / const / integer width / double) and the same return type --
 the drift a Rust compiler would NOT catch either (an FFI declaration is taken on faith)."""
 import os
@@ -13,8 +13,15 @@ RUST_TO_C = {
 }
 
 
+def _rust_sources():
+    out = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rust")):
+        out += [os.path.join(dirpath, f) for f in files if f.endswith(".rs")]
+    return sorted(out)
+
+
 def _rust_decls():
-    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    text = "\n".join(open(f).read() for f in _rust_sources())
     decls = {}
     for block in re.findall(r'extern "C" \{(.*?)\n\}', text, flags=re.S):
         block = re.sub(r"//[^\n]*", "", block)
@@ -67,9 +74,24 @@ def _shape_c(t, has_name=True):
     return depth, const, base
 
 
+def test_integration_md_shows_the_files_it_names():
+    """INTEGRATION.md includes the binding by reference: every rust/ path it names exists, and the FFI excerpt it prints
+    is the head of rust/src/bootstrap/hip.rs word for word."""
+    import re as _re
+
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for path in set(_re.findall(r"\((rust/[^)]+)\)", md)):
+        assert os.path.exists(os.path.join(ROOT, path)), path
+    hip = open(os.path.join(ROOT, "rust", "src", "bootstrap", "hip.rs")).read()
+    m = _re.search(r"Its head:\n\n```rust\n(.*?)// \.\.\. \(constants", md, flags=_re.S)
+    assert m and m.group(1) in hip
+
+
 def test_rust_ffi_block_matches_the_header():
     rust, c = _rust_decls(), _c_decls()
-    assert len(rust) >= 12, sorted(rust)
+    assert len(_rust_sources()) >= 3
+    assert len(rust) >= 20, sorted(rust)
+    assert "tfhe_hip_pool_batch_gate_dev" in rust and "tfhe_hip_pool_synchronize" in rust
     problems = []
     for name, (rparams, rret) in sorted(rust.items()):
         if name not in c:
