@@ -453,11 +453,14 @@ def main():
         hsrc.update(name.encode())  # device code only (the same list as profiles/pmc_roofline.py)
         hsrc.update(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", name), "rb").read())
     csrc_sha = hsrc.hexdigest()[:16]
+    cur_plan = eng.describe_dispatch(B)
     pm, traffic_source = {}, "none: no profiles/pmc_roofline.json entry for this workload"
     try:
         for entry in json.load(open(os.path.join(ROOT, "profiles", "pmc_roofline.json"))):
             if entry["config"] == {"params": args.params, "batch": B, "gate": args.gate}:
-                if entry.get("source", {}).get("csrc_sha256") == csrc_sha:
+                # same device code AND (entries that record it) the same dispatch plan: the rules that pick kernels and
+                # grids are host code, outside the digest
+                if entry.get("source", {}).get("csrc_sha256") == csrc_sha and entry.get("dispatch") in (None, cur_plan):
                     pm = entry
                     traffic_source = f"profiles/pmc_roofline.json entry '{entry['tag']}' (separate --pmc passes, same kernel sources {csrc_sha})"
                 elif not pm:

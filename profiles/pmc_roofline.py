@@ -92,12 +92,29 @@ def source_stamp():
     return stamp
 
 
+def dispatch_of_trace_run():
+    """The dispatch plan of the traced run (bench.py prints what tfhe_hip_describe_dispatch returned): the host-side
+    rules that pick kernels and grids live in tfhe_hip.hip, outside the device-code digest, so the plan itself is
+    recorded and bench.py quotes the entry only for the same plan."""
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(args.pmc)), args.tag + "_trace_bench.json")
+    try:
+        return json.loads(open(path).readline())["roofline"].get("dispatch")
+    except (OSError, ValueError, KeyError, IndexError):
+        return None
+
+
 entry = {
     "tag": args.tag,
     "source": source_stamp(),
     "config": {"params": args.params, "batch": args.batch, "gate": args.gate},
+    "dispatch": dispatch_of_trace_run(),
+    "kernels_in_trace": sorted({r["kernel"].split("(")[0].replace("void ", "") for r in stats if "tfhe::" in r["kernel"]}),
     "blind_rotate": kernel_entry("k_blind_rotate<"),
     "key_switch": kernel_entry("k_key_switch"),
 }
+if any("k_ks_digits" in r["kernel"] for r in stats):
+    entry["key_switch_digits"] = kernel_entry("k_ks_digits")
 json.dump(entry, sys.stdout, indent=1)
 print()
