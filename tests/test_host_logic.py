@@ -288,3 +288,15 @@ def test_keyed_engine_pool_logic(monkeypatch):
     with B.keyed_engine(keys[5], device=1) as v:
         assert v.device == 1 and len(contexts) == 2
     assert B.engine_for(P, 0) is contexts[0]
+
+
+def test_profiles_readme_counter_block_is_generated_from_the_entries():
+    """profiles/README.md's per-launch counter paragraphs are the output of profiles/readme_counters.py over
+    profiles/pmc_roofline.json (round 3's README printed round 2's HBM figure for the `r3` entry): no drift."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("readme_counters", os.path.join(ROOT, "profiles", "readme_counters.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    assert mod.block() in text, "run `python3 profiles/readme_counters.py --install`"
