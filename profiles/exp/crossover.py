@@ -46,5 +46,5 @@ if __name__ == "__main__":
         child(int(sys.argv[1]), int(sys.argv[2]))
     else:
         for wm, ks in ((0, 0), (100000, 100000)):
-            env = dict(os.environ, TFHE_HIP_WIDE_MAX=str(wm), TFHE_HIP_KS_SPLIT_MAX=str(ks))
+            env = dict(os.environ, TFHE_HIP_WIDE_MAX=str(wm), TFHE_HIP_KS_SPLIT_MAX=str(ks), TFHE_HIP_PAIR_MAX="0")  # numeric overrides: experiment builds only (TFHE_HIP_LIB=libtfhe_v_*.so)
             subprocess.run([sys.executable, os.path.abspath(__file__), str(wm), str(ks)], env=env)

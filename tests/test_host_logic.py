@@ -290,6 +290,50 @@ def test_keyed_engine_pool_logic(monkeypatch):
     assert B.engine_for(P, 0) is contexts[0]
 
 
+def test_adopted_views_count_against_the_resident_key_cap(monkeypatch):
+    """bootstrap.adopt_view (what SecretKey.cloud_key() registers a freshly generated key with) shares the LRU eviction
+    of keyed_engine: a loop of key generations keeps at most MAX_RESIDENT_KEYS views resident (each pins 276 MB of device
+    memory and its CloudKey on the host) instead of growing without bound; a view in use is never dropped, and
+    re-adopting the same key object replaces its idle stale view."""
+    import threading
+
+    from rs_tfhe_amd import bootstrap as B
+    from rs_tfhe_amd.params import SECURITY_128_BIT as P
+
+    class FakeView:
+        def __init__(self):
+            self.params, self.device = P, 0
+            self._key, self._last_use, self._users, self.lock = None, 0, 0, threading.RLock()
+            self.closed = False
+
+        def close(self):
+            self.closed = True
+
+    monkeypatch.setattr(B, "_engines", {})
+    monkeypatch.setattr(B, "_views", {})
+
+    class Key:
+        params = P
+
+    keys, views = [Key() for _ in range(7)], [FakeView() for _ in range(7)]
+    for k, v in zip(keys[:4], views[:4]):
+        B.adopt_view(k, v)
+    assert len(B._views[(P, 0)]) == 4 and not any(v.closed for v in views[:4])
+    views[1]._users = 1  # in use: must survive
+    B.adopt_view(keys[4], views[4])  # evicts the least recently used idle view: views[0]
+    assert views[0].closed and not views[1].closed and len(B._views[(P, 0)]) == 4
+    B.adopt_view(keys[5], views[5])  # views[1] is in use: views[2] goes
+    assert views[2].closed and not views[1].closed
+    for i in range(40):  # key rotation: bounded
+        B.adopt_view(Key(), FakeView())
+        assert len(B._views[(P, 0)]) <= B.MAX_RESIDENT_KEYS
+    assert not views[1].closed
+    stale, fresh = FakeView(), FakeView()
+    B.adopt_view(keys[6], stale)
+    B.adopt_view(keys[6], fresh)  # the same CloudKey object generated into another view
+    assert stale.closed and B._views[(P, 0)][id(keys[6])] is fresh
+
+
 def test_profiles_readme_counter_block_is_generated_from_the_entries():
     """profiles/README.md's per-launch counter paragraphs are the output of profiles/readme_counters.py over
     profiles/pmc_roofline.json (round 3's README printed round 2's HBM figure for the `r3` entry): no drift."""
