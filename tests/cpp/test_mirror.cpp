@@ -33,6 +33,13 @@ int hipDeviceSynchronize(void);
 using namespace rs_tfhe;
 
 static int failures = 0;
+#include <chrono>
+static std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+static void lap(const char *what) {  // where the test's time goes (printed, not asserted)
+  const auto t = std::chrono::steady_clock::now();
+  std::printf("[%6.1f s] %s\n", std::chrono::duration<double>(t - g_t0).count(), what);
+  g_t0 = t;
+}
 #define CHECK(cond, ...)                              \
   do {                                                \
     if (!(cond)) {                                    \
@@ -211,6 +218,7 @@ int main() {
     CHECK(decrypt_bool(g.nand(encrypt_bool(true, P, key), encrypt_bool(false, P, key), *slot), key) == true, "address reuse re-uploads");
     delete slot;
 
+    lap("gates, bootstraps, LUTs, GPU keygen, TLWE arithmetic");
     // ---- two threads, two keys, alternating (bootstrap/mod.rs:23: strategies are Send + Sync and every call
     // names its &CloudKey): each thread must always compute under ITS key.  A shared context whose key is
     // checked and then used in two steps fails this; one key view per key on ONE context passes it.
@@ -241,6 +249,7 @@ int main() {
       CHECK(tfhe_hip_key_parent(b1.handle()) == base.ctx() && tfhe_hip_key_is_loaded(b2.handle()) == 1, "views of the shared context");
       CHECK(base.resident_keys() >= 2 && base.resident_keys() <= Engine::kMaxResidentKeys, "resident key views: %zu", base.resident_keys());
     }
+    lap("two threads, two keys");
     // several devices behind one handle (here: two contexts on GPU 0): same words as the single-context path,
     // in input order, at a count that does not divide evenly
     {
@@ -261,6 +270,7 @@ int main() {
       for (size_t i = 0; same && i < one.size(); ++i) same = one[i].p == two[i].p && tlwe::decrypt_bool(two[i], sk.key_lv0) == want[i];
       CHECK(same, "pool of two contexts equals the single-context batch word for word");
     }
+    lap("pool of two contexts, host pointers");
     // ... and for a batch that is RESIDENT on one member's GPU (tfhe_hip_pool_batch_*_dev): device pointers in, the
     // shards travel between the members, device pointer out, input order kept; home = the second member
     {
@@ -296,6 +306,7 @@ int main() {
       hipFree(db);
       hipFree(dout);
     }
+    lap("pool of two contexts, device-resident batch");
     // tfhe_hip_last_error is per (thread, handle): `Bootstrap: Send + Sync` (bootstrap/mod.rs:23) lets two threads
     // share one context; the thread that fails must read ITS text while the other keeps working (and sees none)
     {
@@ -304,28 +315,27 @@ int main() {
       ChaChaRng r(23);
       Ciphertext ca = tlwe::encrypt_bool(true, P.alpha_lv0, sk.key_lv0, r);
       std::atomic<int> bad{0};
-      std::atomic<bool> stop{false};
       std::thread failing([&] {
         std::vector<Torus> out(P.n + 1);
-        for (int it = 0; it < 200; ++it) {
+        for (int it = 0; it < 60; ++it) {
           const int rc = tfhe_hip_batch_gate(h, 99, ca.p.data(), ca.p.data(), out.data(), 1);
           if (rc != TFHE_HIP_EINVAL || std::string(tfhe_hip_last_error(h)) != "unknown gate") ++bad;
           const int rc2 = tfhe_hip_batch_sample_extract(h, nullptr, 5000, nullptr, 1);
           if (rc2 != TFHE_HIP_EINVAL || std::string(tfhe_hip_last_error(h)) != "extraction index out of range") ++bad;
         }
       });
-      std::thread working([&] {
+      std::thread working([&] {  // a bounded number of gates: std::mutex is not fair, an endless worker could starve the other thread
         std::vector<Torus> out(P.n + 1);
-        while (!stop.load()) {
+        for (int it = 0; it < 40; ++it) {
           if (tfhe_hip_batch_gate(h, TFHE_HIP_NAND, ca.p.data(), ca.p.data(), out.data(), 1) != TFHE_HIP_OK) ++bad;
           if (std::string(tfhe_hip_last_error(h)) != "") ++bad;  // another thread's failure is not this thread's
         }
       });
       failing.join();
-      stop = true;
       working.join();
       CHECK(bad.load() == 0, "per-thread error text: %d mismatches", bad.load());
     }
+    lap("per-thread error text");
     // OS-keyed generation (the default): a usable key, different every time
     {
       rs_tfhe::SecretKey sk3 = rs_tfhe::SecretKey::generate(P);
@@ -338,6 +348,7 @@ int main() {
       CHECK(a1() == a2() && a1() != a3(), "ChaChaRng(seed) is reproducible");
     }
   }
+  lap("OS-keyed generation");
   std::printf(failures ? "%d FAILURES\n" : "all C++ mirror tests passed (%d failures)\n", failures);
   return failures ? 1 : 0;
 }

@@ -29,7 +29,10 @@ def test_cpp_mirror_runs_on_gpu():
     exe = os.path.join(CPP, "build", "test_mirror")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", CPP])
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    # the oracle's key generation and the host-side checks use OpenMP: keep the team within the container's CPU quota
+    # (a 256-thread team on 16 CPUs' worth of time tripled the run)
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "16"))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-2000:]
     assert "all C++ mirror tests passed" in r.stdout
