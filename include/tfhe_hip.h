@@ -37,7 +37,8 @@
  *
  * Thread safety: a context may be used from several host threads (the
  * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23); calls on one
- * context are serialised internally.
+ * context are serialised internally, first come first served (a thread that
+ * issues calls back to back cannot starve the others).
  */
 #ifndef TFHE_HIP_H
 #define TFHE_HIP_H

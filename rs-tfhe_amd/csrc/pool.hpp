@@ -20,7 +20,7 @@ struct tfhe_hip_pool {
   tfhe_hip_pool *parent = nullptr;  // non-null: a key view of `parent` (same devices, streams, staging, communicator and mutex)
   int views = 0;                    // live key views (root only)
   bool dying = false;               // destroyed while views were alive: the last view to go frees the pool
-  std::mutex own_mu;  // one call at a time per ROOT pool: a view's calls serialise with its parent's (they share streams and staging)
+  FairMutex own_mu;  // one call at a time per ROOT pool, first come first served: a view's calls serialise with its parent's (they share streams and staging)
   uint64_t id = g_next_handle_id.fetch_add(1);  // key of the per-thread error text (err_slot)
   bool replicated_by_rccl = false;  // how the last key reached the members (tfhe_hip_pool_key_transport)
   // ---- root only: what the device-resident (_dev) calls and the key replication share ----
@@ -202,7 +202,7 @@ bool replicate_key_rccl(tfhe_hip_pool *p) {
   const size_t bytes[3] = {(size_t)P.n * 2 * P.l * 2 * kN * sizeof(double),
                            (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4, (size_t)2 * kN * 4};
   // the members' own mutexes: a member borrowed with tfhe_hip_pool_ctx() and used from another thread waits
-  std::vector<std::unique_lock<std::mutex>> held;
+  std::vector<std::unique_lock<FairMutex>> held;
   for (int i = 0; i < n; ++i) {
     tfhe_hip_ctx *c = p->ctxs[(size_t)i];
     held.emplace_back((c->parent ? c->parent : c)->mu);
@@ -558,7 +558,7 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
     tfhe_hip_pool *root = p->parent;
     bool last_of_dying = false;
     {
-      std::lock_guard<std::mutex> lk(root->own_mu);
+      std::lock_guard<FairMutex> lk(root->own_mu);
       for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);  // (drains the member's queued work first)
       last_of_dying = --root->views == 0 && root->dying;
     }
@@ -570,7 +570,7 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
   {
     // destroyed before its views (the header asks for the opposite order): they share this pool's mutex, staging and
     // communicator, so it stays alive until the last of them goes
-    std::lock_guard<std::mutex> lk(p->own_mu);
+    std::lock_guard<FairMutex> lk(p->own_mu);
     if (p->views > 0) {
       p->dying = true;
       return;
@@ -611,7 +611,7 @@ int tfhe_hip_pool_key_create(tfhe_hip_pool *pool, tfhe_hip_pool **out) {
   *out = nullptr;
   if (!pool) return TFHE_HIP_EINVAL;
   tfhe_hip_pool *root = pool->root();
-  std::lock_guard<std::mutex> lk(root->own_mu);
+  std::lock_guard<FairMutex> lk(root->own_mu);
   tfhe_hip_pool *v = new tfhe_hip_pool();
   v->parent = root;
   for (auto *c : root->ctxs) {
@@ -655,7 +655,7 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 
 #define POOL_ENTER(p)               \
   if (!(p)) return TFHE_HIP_EINVAL; \
-  std::lock_guard<std::mutex> plk_((p)->root()->own_mu)
+  std::lock_guard<FairMutex> plk_((p)->root()->own_mu)
 #define POOL_FIRST(p, call)                                                                                        \
   do {                                                                                                             \
     const int rc_ = (call);                                                                                        \

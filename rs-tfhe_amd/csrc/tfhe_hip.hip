@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -52,6 +53,32 @@ inline std::string &err_slot(uint64_t id) { return t_errors[id]; }  // (referenc
 
 constexpr int kKsG = 32;  // ciphertexts per key-switch workgroup
 
+// Calls on one handle are serialised IN ARRIVAL ORDER (a ticket lock).  std::mutex makes no such promise: a thread that
+// issues calls back to back re-acquires it before a waiting thread wakes, and under `Send + Sync` use (a Rayon team
+// calling Bootstrap::bootstrap on one strategy, src/bootstrap/mod.rs:23) one worker could starve the rest for as long
+// as it had work -- seen in tests/cpp/test_mirror.cpp, where 400 failing calls took minutes beside a thread that kept
+// bootstrapping.
+class FairMutex {
+ public:
+  void lock() {
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t ticket = next_++;
+    cv_.wait(lk, [&] { return serving_ == ticket; });
+  }
+  void unlock() {
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      ++serving_;
+    }
+    cv_.notify_all();
+  }
+
+ private:
+  std::mutex m_;
+  std::condition_variable cv_;
+  uint64_t next_ = 0, serving_ = 0;
+};
+
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
@@ -87,7 +114,7 @@ struct tfhe_hip_ctx {
   DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out, ks_dig;  // scratch / host-API staging (ks_dig: key-switch digit bytes)
   PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
   bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
-  std::mutex mu;
+  FairMutex mu;  // one call at a time per context, first come first served
   uint64_t id = g_next_handle_id.fetch_add(1);  // key of this context's per-thread error text (err_slot)
   bool profiling = false;
   int num_cus = 0;
@@ -150,7 +177,7 @@ struct KeyBind {
 #define ENTER(ctx)                                                                     \
   tfhe_hip_ctx *self_ = (ctx);                                                         \
   if (self_->parent) (ctx) = self_->parent;                                            \
-  std::lock_guard<std::mutex> lk_((ctx)->mu);                                          \
+  std::lock_guard<FairMutex> lk_((ctx)->mu);                                           \
   KeyBind kb_((ctx), &self_->own);                                                     \
   DeviceGuard dg_((ctx)->device);                                                      \
   if (dg_.err != hipSuccess) {                                                         \
@@ -1093,7 +1120,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     tfhe_hip_ctx *base = ctx->parent;
     bool last_of_dying = false;
     {
-      std::lock_guard<std::mutex> lk(base->mu);
+      std::lock_guard<FairMutex> lk(base->mu);
       DeviceGuard dg(base->device);
       if (base->scratch_owned && base->scratch_owner != base->stream) (void)hipStreamSynchronize(base->scratch_owner);
       if (base->stream) (void)hipStreamSynchronize(base->stream);
@@ -1107,7 +1134,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   {
     // Destroyed before its views (the header asks for the opposite order): the views still run on this context's
     // stream, scratch and mutex, so keep it alive until the last of them goes.
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<FairMutex> lk(ctx->mu);
     if (ctx->views > 0) {
       ctx->dying = true;
       return;
@@ -1143,7 +1170,7 @@ int tfhe_hip_key_create(tfhe_hip_ctx *ctx, tfhe_hip_ctx **out) {
   *out = nullptr;
   if (!ctx) return TFHE_HIP_EINVAL;
   tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;  // a view of a view is a view of the same context
-  std::lock_guard<std::mutex> lk(base->mu);
+  std::lock_guard<FairMutex> lk(base->mu);
   tfhe_hip_ctx *v = new tfhe_hip_ctx();
   v->P = base->P;
   v->device = base->device;
@@ -1158,7 +1185,7 @@ tfhe_hip_ctx *tfhe_hip_key_parent(tfhe_hip_ctx *key) { return key ? (key->parent
 int tfhe_hip_key_is_loaded(tfhe_hip_ctx *ctx) {
   if (!ctx) return 0;
   tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
-  std::lock_guard<std::mutex> lk(base->mu);
+  std::lock_guard<FairMutex> lk(base->mu);
   return ctx->own.key_loaded ? 1 : 0;
 }
 
@@ -1327,7 +1354,7 @@ int tfhe_hip_gen_cloud_key_secure(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, co
     if (r < 0) {
       if (errno == EINTR) continue;
       tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
-      std::lock_guard<std::mutex> lk(base->mu);
+      std::lock_guard<FairMutex> lk(base->mu);
       return fail(base, TFHE_HIP_EHIP, std::string("getrandom: ") + strerror(errno));
     }
     got += (size_t)r;

@@ -223,6 +223,57 @@ def test_error_text_is_per_thread(O, keys128):
     eng.close()
 
 
+def test_calls_on_one_context_are_served_in_arrival_order(O, keys128):
+    """`Send + Sync` use of one context: a thread issuing single gates back to back must not starve another thread (a
+    plain mutex is re-acquired by its last owner before a waiter wakes; the context's lock hands out tickets).  While
+    a hog thread bootstraps continuously, every call of a second thread returns within a few single-gate times."""
+    import ctypes as C
+    import time
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pk = _cloud_key(ck)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    ca = sk.encrypt_bool(np.array([1], bool), 4141)
+    lib, ctx = eng._lib, eng._ctx
+    p = lambda x: x.ctypes.data_as(C.c_void_p)  # noqa: E731
+    o0 = np.empty_like(ca)
+    for _ in range(3):
+        assert lib.tfhe_hip_batch_gate(ctx, 0, p(ca), p(ca), p(o0), 1) == 0
+    t0 = time.perf_counter()
+    for _ in range(10):
+        lib.tfhe_hip_batch_gate(ctx, 0, p(ca), p(ca), p(o0), 1)
+    one = (time.perf_counter() - t0) / 10  # one gate alone (about 2.2 ms)
+    stop, waits = threading.Event(), []
+
+    def hog():
+        o = np.empty_like(ca)
+        while not stop.is_set():
+            lib.tfhe_hip_batch_gate(ctx, 0, p(ca), p(ca), p(o), 1)
+
+    def guest():
+        o = np.empty_like(ca)
+        for _ in range(40):
+            t = time.perf_counter()
+            assert lib.tfhe_hip_batch_gate(ctx, 0, p(ca), p(ca), p(o), 1) == 0
+            waits.append(time.perf_counter() - t)
+            time.sleep(0.001)
+
+    th = [threading.Thread(target=hog), threading.Thread(target=guest)]
+    th[0].start()
+    time.sleep(0.02)
+    th[1].start()
+    th[1].join()
+    stop.set()
+    th[0].join()
+    # in arrival order a guest call waits for at most the one call in progress, then runs: ~2 gate times (generous bound)
+    assert max(waits) < 8 * one + 0.01, (max(waits), one)
+    assert sorted(waits)[len(waits) // 2] < 4 * one + 0.005, (sorted(waits)[len(waits) // 2], one)
+    eng.close()
+
+
 @pytest.mark.parametrize("setname,m", [("SECURITY_UINT6", 16), ("SECURITY_UINT7", 16), ("SECURITY_UINT8", 16)])
 def test_pbs_uint6_7_8(O, setname, m):
     """The reference's three largest parameter sets (src/params.rs:293-376): n = 1071 / 1160, key-switch base 64 / 128
