@@ -359,18 +359,26 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
     b.cap = want;
     return TFHE_HIP_OK;
   };
-  auto timed = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, int member, hipStream_t s, bool begin) {
-    if (!root->timing) return;
+  // transfer timing: begin records the first event of a new pair on `s` and returns the pair's index (-1: off), end
+  // records the second event of pair `idx`
+  auto timed_begin = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, int member, hipStream_t s) -> long {
+    if (!root->timing) return -1;
     (void)hipSetDevice(p->ctxs[(size_t)member]->device);
-    if (begin) {
-      hipEvent_t a = nullptr, b = nullptr;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-      (void)hipEventRecord(a, s);
-      v.emplace_back(a, b);
-      devs.push_back(member);
-    } else if (!v.empty()) {
-      (void)hipEventRecord(v.back().second, s);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreate(&a) != hipSuccess) return -1;
+    if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      return -1;
     }
+    (void)hipEventRecord(a, s);
+    v.emplace_back(a, b);
+    devs.push_back(member);
+    return (long)v.size() - 1;
+  };
+  auto timed_end = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, long idx, int member, hipStream_t s) {
+    if (idx < 0) return;
+    (void)hipSetDevice(p->ctxs[(size_t)member]->device);
+    (void)hipEventRecord(v[(size_t)idx].second, s);
   };
   // shard table: shard r -> member, [lo, hi), remote?
   struct Sh {
@@ -407,12 +415,14 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   if (any_remote) {
     root->last_transport = comms ? "rccl" : "peer-copy";
     if (comms) {
+      std::vector<long> tix(shards.size(), -1);
+      for (size_t q = 0; q < shards.size(); ++q)  // (events go in before the group opens: inside it nothing is enqueued yet)
+        if (shards[q].remote) tix[q] = timed_begin(root->ev_scatter, root->ev_scatter_dev, shards[q].member, member_stream(shards[q].member));
       if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (scatter)");
-      bool good = true;
+      bool good = true;  // (a group that was opened is always closed, whatever fails inside it)
       for (const Sh &sh : shards) {
         if (!sh.remote) continue;
         tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
-        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, member_stream(sh.member), true);
         for (int k = 0; k < 5 && good; ++k) {
           if (!ins[k].ptr) continue;
           const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
@@ -425,9 +435,9 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         }
       }
       good = (R.GroupEnd() == ncclSuccess) && good;
+      for (size_t q = 0; q < shards.size(); ++q)
+        if (shards[q].remote) timed_end(root->ev_scatter, tix[q], shards[q].member, member_stream(shards[q].member));
       if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL scatter (ncclSend / ncclRecv) failed");
-      for (const Sh &sh : shards)
-        if (sh.remote) timed(root->ev_scatter, root->ev_scatter_dev, sh.member, member_stream(sh.member), false);
     } else {
       hipError_t e = hipSetDevice(hctx->device);
       if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
@@ -445,7 +455,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         hipStream_t ms = member_stream(sh.member);
         if ((e = hipSetDevice(ddev)) != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
         if ((e = hipStreamWaitEvent(ms, root->ready, 0)) != hipSuccess) return hipfail("hipStreamWaitEvent", e, sh.member);
-        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, ms, true);
+        const long tix = timed_begin(root->ev_scatter, root->ev_scatter_dev, sh.member, ms);
         for (int k = 0; k < 5; ++k) {
           if (!ins[k].ptr) continue;
           const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
@@ -454,7 +464,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
             return hipfail("hipMemcpyPeerAsync (scatter)", e, sh.member);
           root->scatter_bytes += bytes;
         }
-        timed(root->ev_scatter, root->ev_scatter_dev, sh.member, ms, false);
+        timed_end(root->ev_scatter, tix, sh.member, ms);
       }
     }
   }
@@ -481,9 +491,9 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   // 4. gather
   if (any_remote) {
     if (comms) {
+      const long gix = timed_begin(root->ev_gather, root->ev_gather_dev, home, hrt);
       if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (gather)");
       bool good = true;
-      timed(root->ev_gather, root->ev_gather_dev, home, hrt, true);
       for (const Sh &sh : shards) {
         if (!sh.remote || !good) continue;
         tfhe_hip_pool::Stage &st = root->stage[(size_t)sh.member];
@@ -495,8 +505,8 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         root->gather_bytes += bytes;
       }
       good = (R.GroupEnd() == ncclSuccess) && good;
+      timed_end(root->ev_gather, gix, home, hrt);
       if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL gather (ncclSend / ncclRecv) failed");
-      timed(root->ev_gather, root->ev_gather_dev, home, hrt, false);
     } else {
       for (const Sh &sh : shards) {
         if (!sh.remote) continue;
@@ -506,10 +516,10 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         const size_t bytes = (sh.hi - sh.lo) * out_row_bytes;
         hipError_t e = hipSetDevice(sdev);
         if (e != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
-        timed(root->ev_gather, root->ev_gather_dev, sh.member, ms, true);
+        const long gix = timed_begin(root->ev_gather, root->ev_gather_dev, sh.member, ms);
         if ((e = hipMemcpyPeerAsync((unsigned char *)out + sh.lo * out_row_bytes, hctx->device, st.out.p, sdev, bytes, ms)) != hipSuccess)
           return hipfail("hipMemcpyPeerAsync (gather)", e, sh.member);
-        timed(root->ev_gather, root->ev_gather_dev, sh.member, ms, false);
+        timed_end(root->ev_gather, gix, sh.member, ms);
         if ((e = hipEventRecord(st.done, ms)) != hipSuccess) return hipfail("hipEventRecord", e, sh.member);
         root->gather_bytes += bytes;
       }
