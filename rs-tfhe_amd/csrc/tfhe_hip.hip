@@ -957,16 +957,6 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     g_create_error = "unsupported parameter set";
     return TFHE_HIP_EINVAL;
   }
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev <= 0) {
-    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
-    return TFHE_HIP_EHIP;
-  }
-  if (device < 0 || device >= ndev) {
-    g_create_error = "device ordinal out of range";
-    return TFHE_HIP_EINVAL;
-  }
   // The supported controls (include/tfhe_hip.h): force ONE kernel at every batch size.  The parity suite uses them to
   // hold every shipped kernel to the CPU checker; they never change result bits.  (Validated before anything is allocated.)
   int br_force = 0, ks_force = 0;
@@ -998,6 +988,16 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
       return TFHE_HIP_EINVAL;
     }
     ks_force = k + 1;
+  }
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device: ") + hipGetErrorString(e);
+    return TFHE_HIP_EHIP;
+  }
+  if (device < 0 || device >= ndev) {
+    g_create_error = "device ordinal out of range";
+    return TFHE_HIP_EINVAL;
   }
   tfhe_hip_ctx *ctx = new tfhe_hip_ctx();
   ctx->P = *p;

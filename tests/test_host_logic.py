@@ -63,6 +63,33 @@ def test_ctx_create_rejects_bad_params_without_gpu():
     lib.tfhe_hip_ctx_destroy(None)  # no-op
 
 
+def test_kernel_selectors_are_validated_without_gpu(monkeypatch):
+    """TFHE_HIP_BR_KERNEL / TFHE_HIP_KS_KERNEL (the supported controls listed in include/tfhe_hip.h) are checked before
+    the library touches a device: unknown values, and kernels the parameter set cannot run, are TFHE_HIP_EINVAL with a
+    message; every variable the library reads is in the header's list."""
+    from rs_tfhe_amd import _capi
+
+    lib = _capi.lib()
+    ctx = ctypes.c_void_p()
+    good, uint4 = _capi.Params(700, 3, 6, 2, 9), _capi.Params(820, 1, 22, 5, 3)
+    for var, val, params, text in (("TFHE_HIP_KS_KERNEL", "nonsense", good, b"TFHE_HIP_KS_KERNEL must be"),
+                                   ("TFHE_HIP_BR_KERNEL", "wide", good, b"TFHE_HIP_BR_KERNEL must be"),
+                                   ("TFHE_HIP_KS_KERNEL", "mfma", uint4, b"not available"),
+                                   ("TFHE_HIP_KS_KERNEL", "sliced", good, b"not available")):
+        monkeypatch.setenv(var, val)
+        assert lib.tfhe_hip_ctx_create(ctypes.byref(params), 0, ctypes.byref(ctx)) == _capi.EINVAL, (var, val)
+        assert text in lib.tfhe_hip_last_error(None), lib.tfhe_hip_last_error(None)
+        monkeypatch.delenv(var)
+    # the product library reads exactly the variables the header lists
+    src = "".join(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", f)).read() for f in ("tfhe_hip.hip", "pool.hpp"))
+    product = re.sub(r"#ifdef TFHE_EXPERIMENT.*?\n#endif\n#endif\n", "", src, flags=re.S)  # the experiment-only overrides
+    read = set(re.findall(r'getenv\("(TFHE_HIP_[A-Z0-9_]+)"\)', product))
+    hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
+    assert read == {"TFHE_HIP_BR_KERNEL", "TFHE_HIP_KS_KERNEL", "TFHE_HIP_POOL_RCCL", "TFHE_HIP_POOL_PINNED_STAGING"}, read
+    for v in read:
+        assert v in hdr
+
+
 def test_pool_create_and_shard_without_gpu():
     """tfhe_hip_pool_*: argument checks and the order-preserving split (rayon_impl.rs:40-47 keeps input order)."""
     from rs_tfhe_amd import _capi
