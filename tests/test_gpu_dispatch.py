@@ -223,6 +223,31 @@ def test_error_text_is_per_thread(O, keys128):
     eng.close()
 
 
+def test_sliced_key_switch_in_slabs(O, monkeypatch):
+    """The column-sliced key switch bounds its digit scratch by cutting a launch into slabs of 131,072 ciphertexts: a
+    batch of 133,000 (one full slab + a ragged second one) must equal the generic kernel word for word, and a sample of
+    it the CPU path."""
+    import rs_tfhe_amd as R
+
+    op = O.SECURITY_UINT4
+    sk, ck = oracle_keys(O, op)
+    pk = _cloud_key(ck)
+    count = 133000
+    rng = np.random.default_rng(555)
+    lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint32)
+    outs = {}
+    for kernel in ("sliced", "generic"):
+        monkeypatch.setenv("TFHE_HIP_KS_KERNEL", kernel)
+        eng = R.Engine(pk.params, 0)
+        eng.load_cloud_key(pk)
+        assert f"key_switch={kernel}" in eng.describe_dispatch(count)
+        outs[kernel] = eng.batch_identity_key_switch(lv1)
+        eng.close()
+    assert np.array_equal(outs["sliced"], outs["generic"])
+    idx = np.r_[0:8, 131068:131080, count - 8:count]  # both sides of the slab boundary, both ends
+    assert np.array_equal(outs["sliced"][idx], O.batch_identity_key_switching(ck, lv1[idx]))
+
+
 def test_calls_on_one_context_are_served_in_arrival_order(O, keys128):
     """`Send + Sync` use of one context: a thread issuing single gates back to back must not starve another thread (a
     plain mutex is re-acquired by its last owner before a waiter wakes; the context's lock hands out tickets).  While
