@@ -329,8 +329,17 @@ __global__ __launch_bounds__(320) void k_key_switch_split(const uint32_t *__rest
 // Lane map: 16 lanes cover the 64 columns (4 each); the 4 lane-quarters of a wave serve 4 different ciphertexts per
 // instruction (ds_read_b128 is serviced in 16-lane groups, so different rows per quarter cost nothing); S accumulator
 // sets per lane -> 4*S ciphertexts per wave, 16*S per workgroup of 4 waves.
-constexpr int kKsSlWaves = 4;
-__host__ __device__ constexpr int ks_sliced_cts(int sets) { return 4 * sets * kKsSlWaves; }  // ciphertexts per workgroup (512 at S = 32)
+// Waves per workgroup: four, two workgroups per CU, while two rings fit a CU's LDS (base 16 / 32); EIGHT in ONE workgroup
+// per CU at base 64 / 128, whose rings (16 / 32 KiB per group) leave room for one workgroup only -- the same two waves
+// per SIMD, one ring and one digit stage for twice the ciphertexts (half the L2 -> LDS traffic per ciphertext).
+#ifndef TFHE_KS_SL2_WAVES_WIDE  // (experiment knob: 4 = the four-wave workgroup at base 64 / 128 too)
+#define TFHE_KS_SL2_WAVES_WIDE 8
+#endif
+#ifndef TFHE_KS_SL2_WAVES_B32  // (experiment knob: 8 = one eight-wave workgroup per CU at base 32 as well; base 16's 4 KiB groups are 4 DMAs)
+#define TFHE_KS_SL2_WAVES_B32 4
+#endif
+__host__ __device__ constexpr int ks_sl2_waves(int basebit) { return basebit <= 4 ? 4 : basebit == 5 ? TFHE_KS_SL2_WAVES_B32 : TFHE_KS_SL2_WAVES_WIDE; }
+__host__ __device__ constexpr int ks_sl2_cts(int basebit, int sets) { return 4 * sets * ks_sl2_waves(basebit); }  // ciphertexts per workgroup (512 at S = 32, four waves)
 
 // The kernel's first form (rounds 1-3: digits extracted per read with v_bfe + v_lshl_add, four v_sub per row read, a_bar
 // words restaged every 16 coefficients behind a drained DMA queue, one barrier per group; 12.4-13.5 ms for 65,536
@@ -351,22 +360,29 @@ template <int BASEBIT>
 struct KsSl2 {
   static constexpr int BASE = 1 << BASEBIT;
   static constexpr int SLOT = BASE * 256;            // bytes of one group's slice: BASE rows x 64 columns
-  static constexpr int PWG = SLOT / 1024 / kKsSlWaves;  // ring DMA instructions per wave per group (1 KiB each)
+  static constexpr int CW = ks_sl2_waves(BASEBIT);   // waves per workgroup
+  static constexpr int PWG = SLOT / 1024 / CW;       // ring DMA instructions per wave per group (1 KiB each)
   static_assert(PWG >= 1, "a group's slice must be at least one DMA instruction per wave (base >= 16)");
 };
-__host__ __device__ constexpr int ks_sl2_stage_words(int sets) { return (ks_sliced_cts(sets) + 255) / 256 * 256; }  // per quad, padded to whole DMA rounds
-__host__ __device__ constexpr size_t ks_sl2_lds_bytes(int basebit, int sets, int rp) {
-  return (size_t)2 * rp * ((size_t)(1 << basebit) * 256) + (size_t)2 * ks_sl2_stage_words(sets) * 4;
+// stage words per quad: one per ciphertext, padded so that every wave issues the same whole number of 256-byte DMAs
+__host__ __device__ constexpr int ks_sl2_stage_words(int basebit, int sets) {
+  return (ks_sl2_cts(basebit, sets) + 64 * ks_sl2_waves(basebit) - 1) / (64 * ks_sl2_waves(basebit)) * (64 * ks_sl2_waves(basebit));
 }
-// pairs of groups in the ring: 4 (lookahead 6 groups) where two workgroups still share a CU's LDS, else 2
+__host__ __device__ constexpr size_t ks_sl2_lds_bytes(int basebit, int sets, int rp) {
+  return (size_t)2 * rp * ((size_t)(1 << basebit) * 256) + (size_t)2 * ks_sl2_stage_words(basebit, sets) * 4;
+}
+// pairs of groups in the ring: 4 (lookahead 6 groups) at base 16 / 32, 2 at base 64 / 128
 #ifndef TFHE_KS_SL2_RP_SMALL  // (experiment knob)
 #define TFHE_KS_SL2_RP_SMALL 4
 #endif
-__host__ __device__ constexpr int ks_sl2_rp(int basebit) { return basebit <= 5 ? TFHE_KS_SL2_RP_SMALL : 2; }
+#ifndef TFHE_KS_SL2_RP_B64  // (experiment knob) base 64: 2 pairs (64 KiB); 4 pairs measured no better (11.1 vs 10.9 ms at SECURITY_UINT6)
+#define TFHE_KS_SL2_RP_B64 2
+#endif
+__host__ __device__ constexpr int ks_sl2_rp(int basebit) { return basebit <= 5 ? TFHE_KS_SL2_RP_SMALL : basebit == 6 ? TFHE_KS_SL2_RP_B64 : 2; }
 // rows of the digit buffer: the ciphertexts of whole workgroups plus one DMA round of slack
-__host__ __device__ inline size_t ks_sl2_ct_stride(size_t count, int sets) {
-  const size_t cts = (size_t)ks_sliced_cts(sets);
-  return (count + cts - 1) / cts * cts + 256;
+__host__ __device__ inline size_t ks_sl2_ct_stride(size_t count, int basebit, int sets) {
+  const size_t cts = (size_t)ks_sl2_cts(basebit, sets);
+  return (count + cts - 1) / cts * cts + 512;
 }
 
 // The same DMAs with the address split as (wave-uniform 64-bit base in SGPRs) + (per-lane 32-bit offset in ONE VGPR that
@@ -439,14 +455,14 @@ __device__ __forceinline__ void add3_inplace(uint32_t &acc, uint32_t a, uint32_t
 }
 
 template <int BASEBIT, int S, int RP>
-__global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__restrict__ digw, size_t ct_stride,
+__global__ __launch_bounds__(64 * ks_sl2_waves(BASEBIT), 2) void k_key_switch_sliced(const uint32_t *__restrict__ digw, size_t ct_stride,
                                                              const uint32_t *__restrict__ lv1,       // [count][N+1]: the body word
                                                              const unsigned char *__restrict__ ksk,  // engine layout
                                                              int n, int t, uint32_t *__restrict__ out, size_t count) {
   using G = KsSl2<BASEBIT>;
-  constexpr int N = 1024, BASE = G::BASE, SLOT = G::SLOT, PWG = G::PWG, RG = 2 * RP, CTS = ks_sliced_cts(S);
-  constexpr int STW = ks_sl2_stage_words(S);       // stage words per quad (one per ciphertext, padded)
-  constexpr int ST = STW / 64 / kKsSlWaves;        // stage DMA instructions per wave per quad (256 B each)
+  constexpr int N = 1024, BASE = G::BASE, SLOT = G::SLOT, PWG = G::PWG, CW = G::CW, RG = 2 * RP, CTS = ks_sl2_cts(BASEBIT, S);
+  constexpr int STW = ks_sl2_stage_words(BASEBIT, S);  // stage words per quad (one per ciphertext, padded)
+  constexpr int ST = STW / 64 / CW;                    // stage DMA instructions per wave per quad (256 B each)
   constexpr int PW = 2 * PWG;                      // ring DMA instructions per wave per pair
   static_assert(RP == 2 || RP == 4, "ring of 2 or 4 pairs");
   using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__
     const uint32_t gs = g < total ? g : total - 1u;  // (rows gs * BASE + 4x + sub < total * BASE: always inside the key)
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)PWG; ++c) {
-      const uint32_t x = wave + c * kKsSlWaves;
+      const uint32_t x = wave + c * CW;
       glds16_s(ksk + (size_t)(gs * BASE + 4u * x) * row_bytes + col0 * 4u, voff_ring, lds_base + slot * SLOT + x * 1024u);
     }
   };
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(256, 2) void k_key_switch_sliced(const uint32_t *__
     const uint32_t Qs = Q < total / 4u ? Q : total / 4u - 1u;
 #pragma unroll
     for (uint32_t c = 0; c < (uint32_t)ST; ++c) {
-      const uint32_t y = wave + c * kKsSlWaves;
+      const uint32_t y = wave + c * CW;
       glds4_s(digw + (size_t)Qs * ct_stride + ct0 + y * 64u, voff_stage, lds_base + off_stage + (Q & 1u) * (STW * 4u) + y * 256u);
     }
   };

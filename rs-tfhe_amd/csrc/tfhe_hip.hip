@@ -543,12 +543,10 @@ sl2_kernel_t sl2_kernel(int basebit, int sets) {
 // Accumulator sets per lane, chosen per launch so that the grid fills whole rounds of the machine: a workgroup's time is
 // proportional to S, the grid is ceil(count / 16S) x slices workgroups, `slots` of them run at once, so the launch
 // costs ceil(grid / slots) x S (SECURITY_UINT4, 65,536 ciphertexts, 13 slices, 512 slots: S = 32 is 3.25 rounds = 4 x 32,
-// S = 36 is 2.9 rounds = 3 x 36).  Base 64 keeps to the sets whose code does not spill (28: 7.0 ms, 36: 8.1 at
-// SECURITY_UINT3); base 128 (one workgroup per CU) runs best at 36 (26.5 ms vs 28.6 / 31.0 at 32 / 28, SECURITY_UINT7) --
-// profiles/exp/logs/r4_ks_sl_ablation.log.
+// S = 36 is 2.9 rounds = 3 x 36; base 64 / 128 run ONE eight-wave workgroup per CU, 256 slots: SECURITY_UINT7, 19
+// slices: S = 32 is 4.75 rounds = 5 x 32 -- 15.8 ms measured, 16.8 / 17.8 at 36 / 28) -- profiles/exp/logs/r4_ks_sl_ablation.log.
 bool ks_sl2_sets_allowed(int basebit, int sets) {
-  if (basebit == 6) return sets == 24 || sets == 28;
-  if (basebit == 7) return sets == 36;
+  (void)basebit;
   return sets == 24 || sets == 28 || sets == 32 || sets == 36;
 }
 int ks_sl2_pick_sets(int basebit, size_t count, int slices, int slots) {
@@ -556,7 +554,7 @@ int ks_sl2_pick_sets(int basebit, size_t count, int slices, int slots) {
   size_t best_cost = ~(size_t)0;
   for (int sets : {24, 28, 32, 36}) {
     if (!ks_sl2_sets_allowed(basebit, sets)) continue;
-    const size_t grid = ((count + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets)) * (size_t)slices;
+    const size_t grid = ((count + (size_t)ks_sl2_cts(basebit, sets) - 1) / (size_t)ks_sl2_cts(basebit, sets)) * (size_t)slices;
     const size_t cost = ((grid + (size_t)slots - 1) / (size_t)slots) * (size_t)sets;
     if (cost < best_cost || (cost == best_cost && sets == 32)) {
       best = sets;
@@ -616,13 +614,15 @@ KsPlan plan_key_switch(const tfhe_hip_ctx *ctx, size_t count) {
     // while two rings fit a CU's LDS, else one)
     const int slices = (n + 1 + 63) / 64, rp = ks_sl2_rp(P.basebit);
     const size_t in_launch = count < kKsSl2Slab ? count : kKsSl2Slab;
-    const int per_cu = 2 * ks_sl2_lds_bytes(P.basebit, 36, rp) <= 160 * 1024 ? 2 : 1;
+    // workgroups resident per CU: two waves per SIMD by registers (8 wave slots), and the rings must fit the LDS
+    const int by_waves = 8 / ks_sl2_waves(P.basebit), by_lds = 2 * ks_sl2_lds_bytes(P.basebit, 36, rp) <= 160 * 1024 ? 2 : 1;
+    const int per_cu = by_waves < by_lds ? by_waves : by_lds;
     int sets = ks_sl2_pick_sets(P.basebit, in_launch, slices, per_cu * ctx->num_cus);
     if (ctx->ks_sliced_sets) sets = ctx->ks_sliced_sets;
     // small batches have few ciphertext groups: the walk over the N * t groups is cut into up to 64 chunks (grid.z)
     // so that about two workgroups per CU exist; the chunks meet in the zeroed output through integer atomics.
     // A chunk is whole rings (2 * rp groups).
-    const size_t groups = (in_launch + (size_t)ks_sliced_cts(sets) - 1) / (size_t)ks_sliced_cts(sets);
+    const size_t groups = (in_launch + (size_t)ks_sl2_cts(P.basebit, sets) - 1) / (size_t)ks_sl2_cts(P.basebit, sets);
     int kchunks = 1;
     while (kchunks < 64 && groups * (size_t)slices * (size_t)kchunks < 2 * (size_t)ctx->num_cus) kchunks *= 2;
     if (ctx->ks_sl_kchunks) kchunks = ctx->ks_sl_kchunks;
@@ -678,7 +678,7 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
   }
   if (pl.kind == KS_SLICED) {
     const size_t in_launch = count < kKsSl2Slab ? count : kKsSl2Slab;
-    CHK(ensure(ctx, ctx->ks_dig, (size_t)(kN * P.t / 4) * ks_sl2_ct_stride(in_launch, pl.sets) * 4));
+    CHK(ensure(ctx, ctx->ks_dig, (size_t)(kN * P.t / 4) * ks_sl2_ct_stride(in_launch, P.basebit, pl.sets) * 4));
   }
   const int rw4 = ksk_row_words(n) >> 2;
   const int bd = (rw4 + 63) & ~63;  // <= 320 for n <= 1279
@@ -711,12 +711,12 @@ int launch_key_switch(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *lv1, uin
         const unsigned quads = (unsigned)(kN * P.t / 4);
         for (size_t done = 0; done < count; done += kKsSl2Slab) {
           const size_t m = count - done < kKsSl2Slab ? count - done : kKsSl2Slab;
-          const size_t ct_stride = ks_sl2_ct_stride(m, pl.sets);
+          const size_t ct_stride = ks_sl2_ct_stride(m, P.basebit, pl.sets);
           const uint32_t *src = lv1 + done * (size_t)(kN + 1);
           hipLaunchKernelGGL(k_ks_digits, dim3((unsigned)((ct_stride + 63) / 64), quads / 32), dim3(256), 0, s, src,
                              (uint32_t *)ctx->ks_dig.p, ct_stride, m, P.basebit, P.t);
-          const size_t groups = (m + (size_t)ks_sliced_cts(pl.sets) - 1) / (size_t)ks_sliced_cts(pl.sets);
-          hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices, (unsigned)pl.kparts), dim3(256), lds, s,
+          const size_t groups = (m + (size_t)ks_sl2_cts(P.basebit, pl.sets) - 1) / (size_t)ks_sl2_cts(P.basebit, pl.sets);
+          hipLaunchKernelGGL(kern, dim3((unsigned)groups, (unsigned)slices, (unsigned)pl.kparts), dim3(64u * (unsigned)ks_sl2_waves(P.basebit)), lds, s,
                              (const uint32_t *)ctx->ks_dig.p, ct_stride, src, (const unsigned char *)ctx->K->d_ksk, n, P.t,
                              dst + done * (size_t)(n + 1), m);
         }
