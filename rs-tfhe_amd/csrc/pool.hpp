@@ -554,6 +554,22 @@ int tfhe_hip_pool_create(const tfhe_hip_params *params, const int *devices, int 
     }
     p->ctxs.push_back(c);
   }
+  // direct xGMI for the peer-copy transport (key clone, shards of the device-resident calls when no communicator is to be
+  // had): peer access between every pair of distinct devices, where the topology allows it (errors are not fatal: the
+  // runtime stages such copies through the host)
+  {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    for (int i = 0; i < ndev; ++i)
+      for (int j = 0; j < ndev; ++j) {
+        if (devices[i] == devices[j]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) continue;
+        if (hipSetDevice(devices[i]) == hipSuccess) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+      }
+    (void)hipGetLastError();  // (hipErrorPeerAccessAlreadyEnabled and the like)
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
   // several members fed by one host: each stages its pageable shard through a pinned arena of its own (to_dev)
   const char *env = getenv("TFHE_HIP_POOL_PINNED_STAGING");
   const bool stage = env ? atoi(env) != 0 : ndev > 1;
