@@ -508,7 +508,7 @@ __global__ __launch_bounds__(64 * ks_sl2_waves(BASEBIT), 2) void k_key_switch_sl
   uint32_t acc[S][4];
 #pragma unroll
   for (int a = 0; a < S; ++a) acc[a][0] = acc[a][1] = acc[a][2] = acc[a][3] = 0u;
-  const uint32_t lane_col = c4 * 16u;  // address byte 0; byte 1 comes from the digit
+  const uint32_t lane_col = c4 * 16u | 0x10000u;  // address byte 0 (byte 1 comes from the digit); byte 2 = 1 for the slots beyond 64 KiB
   const uint32_t my_ct = wave * (4u * S) + sub;  // + 4a: this lane quarter's ciphertexts within the workgroup
 
   // prologue, in the steady-state order [stage][ring]: the first quad's digits, ring pairs 0 .. RP-2
@@ -544,8 +544,13 @@ __global__ __launch_bounds__(64 * ks_sl2_waves(BASEBIT), 2) void k_key_switch_sl
 #pragma unroll
         for (int a = 0; a < S; ++a) abw[a] = st[my_ct + 4u * a];
       }
-      constexpr uint32_t slot0 = (uint32_t)((2 * p) % RG) * SLOT, slot1 = (uint32_t)((2 * p + 1) % RG) * SLOT;
-      constexpr uint32_t sel0 = 0x0C0C0400u + ((uint32_t)((2 * p) % 4) << 8), sel1 = 0x0C0C0400u + ((uint32_t)((2 * p + 1) % 4) << 8);
+      // slot offsets ride in the ds_read's 16-bit immediate; a slot at or beyond 64 KiB (base 128: slots of 32 KiB) takes
+      // address bit 16 from byte 2 of the lane constant instead (selector byte 2 = 0x02), so it costs no instruction either
+      constexpr uint32_t s0 = (uint32_t)((2 * p) % RG) * SLOT, s1 = (uint32_t)((2 * p + 1) % RG) * SLOT;
+      constexpr uint32_t slot0 = s0 & 0xFFFFu, slot1 = s1 & 0xFFFFu;
+      static_assert(s0 < 0x20000u && s1 < 0x20000u, "ring within 128 KiB");
+      constexpr uint32_t sel0 = (s0 >= 0x10000u ? 0x0C020400u : 0x0C0C0400u) + ((uint32_t)((2 * p) % 4) << 8);
+      constexpr uint32_t sel1 = (s1 >= 0x10000u ? 0x0C020400u : 0x0C0C0400u) + ((uint32_t)((2 * p + 1) % 4) << 8);
       // Software pipeline over batches of GB ciphertexts: the picks and row reads of batch b+1 are issued BEFORE the
       // additions of batch b, so the LDS always has this wave's next reads queued while its VALU adds (with the reads
       // drained per batch the two pipes took turns: 8.4 ms = VALU 3.8 + LDS 4.6 at SECURITY_UINT4).  The batches are
