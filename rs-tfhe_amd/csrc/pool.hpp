@@ -362,7 +362,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   // transfer timing: begin records the first event of a new pair on `s` and returns the pair's index (-1: off), end
   // records the second event of pair `idx`
   auto timed_begin = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, int member, hipStream_t s) -> long {
-    if (!root->timing) return -1;
+    if (!root->timing || v.size() >= 4096) return -1;  // (a caller that never collects: stop at 4,096 pending pairs)
     (void)hipSetDevice(p->ctxs[(size_t)member]->device);
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess) return -1;
