@@ -371,3 +371,27 @@ def test_profiles_readme_counter_block_is_generated_from_the_entries():
     spec.loader.exec_module(mod)
     text = open(os.path.join(ROOT, "profiles", "README.md")).read()
     assert mod.block() in text, "run `python3 profiles/readme_counters.py --install`"
+
+
+def test_measured_tables_are_generated_from_the_committed_bench_lines():
+    """DESIGN.md section 5 and profiles/README.md carry the output of profiles/readme_bench.py over the committed
+    profiles/r4_*bench*.json[l] files, and the headline figures quoted in README.md / DESIGN.md's summary are those of
+    profiles/r4_bench.json: the documents cannot drift from the evidence they cite."""
+    import importlib.util
+    import re
+
+    spec = importlib.util.spec_from_file_location("readme_bench", os.path.join(ROOT, "profiles", "readme_bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    block = mod.block()
+    for doc in ("DESIGN.md", os.path.join("profiles", "README.md")):
+        assert block in open(os.path.join(ROOT, doc)).read(), f"{doc}: run `python3 profiles/readme_bench.py --install`"
+    value, br_ms, ks_ms, frac, frac_alg = mod.headline()
+    want = f"{value / 1e3:.1f} k"
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    m = re.search(r"\*\*([0-9.]+ k) hom_nand bootstraps/s\*\*", readme)
+    assert m and m.group(1) == want, (m and m.group(1), want)
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"Headline: \*\*([0-9.]+ k) `hom_nand` bootstraps/s\*\*", design)
+    assert m and m.group(1) == want, (m and m.group(1), want)
+    assert f"{frac_alg:.3f} of the FP64 vector" in design and f"{frac_alg:.3f} on SURVEY" in readme
