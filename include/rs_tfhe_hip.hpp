@@ -805,4 +805,136 @@ inline std::vector<TRLWELv1> batch_blind_rotate(const std::vector<Ciphertext> &s
 }
 }  // namespace trgsw
 
+// ---- src/proxy_reenc.rs (feature `proxy-reenc`): LWE proxy re-encryption -----------------------------------------
+// Key generation is the client's (host side, as in the reference); reencrypt_tlwe_lv0 -- the proxy's walk over n * t
+// key rows per ciphertext -- runs on the GPU through tfhe_hip_load_reenc_key / tfhe_hip_batch_reencrypt.
+namespace proxy_reenc {
+struct PublicKeyLv0 {  // proxy_reenc.rs:95-99
+  SecurityParams params = DEFAULT_SECURITY;
+  std::vector<Ciphertext> encryptions;  // encryptions of zero
+  static PublicKeyLv0 generate_with_params(const SecretKey &sk, size_t size, double alpha, ChaChaRng &rng) {  // :144-153
+    PublicKeyLv0 pk;
+    pk.params = sk.params;
+    for (size_t i = 0; i < size; ++i) pk.encryptions.push_back(tlwe::encrypt_f64(0.0, alpha, sk.key_lv0, rng));
+    return pk;
+  }
+  static PublicKeyLv0 generate(const SecretKey &sk, ChaChaRng &rng) {  // :125-131
+    return generate_with_params(sk, (size_t)sk.params.n * 2, sk.params.alpha_lv0, rng);
+  }
+  Ciphertext encrypt_f64(double plaintext, double alpha, ChaChaRng &rng) const {  // :168-200
+    Ciphertext r(params.n);
+    r.b_mut() = f64_to_torus(plaintext);
+    for (const Ciphertext &enc : encryptions) {
+      if (rng() & 1u) {  // gen_bool(0.5): join
+        const bool add = rng() & 1u;  // gen_bool(0.5): added or subtracted
+        for (size_t i = 0; i < r.p.size(); ++i) r.p[i] = add ? r.p[i] + enc.p[i] : r.p[i] - enc.p[i];
+      }
+    }
+    std::normal_distribution<double> noise(0.0, alpha);
+    if (alpha > 0) r.b_mut() += f64_to_torus(noise(rng));
+    return r;
+  }
+  Ciphertext encrypt_bool(bool b, double alpha, ChaChaRng &rng) const { return encrypt_f64(b ? 0.125 : -0.125, alpha, rng); }  // :212-215
+};
+
+class ProxyReencryptionKey {  // proxy_reenc.rs:224-233
+ public:
+  SecurityParams params = DEFAULT_SECURITY;  // the ciphertexts' set with THIS key's basebit / t
+  std::vector<Torus> key_encryptions;        // [n][t][base][n+1], index base*t*i + base*j + k; k = 0 entries zero
+  int base() const { return params.base(); }
+  int t() const { return params.iks_t; }
+
+  static ProxyReencryptionKey new_symmetric_with_params(const std::vector<Torus> &key_from, const SecretKey &key_to, double alpha,
+                                                        int basebit, int t, ChaChaRng &rng) {  // :389-425
+    return build(key_from, key_to.params, basebit, t,
+                 [&](double p) { return tlwe::encrypt_f64(p, alpha, key_to.key_lv0, rng); });
+  }
+  static ProxyReencryptionKey new_symmetric(const std::vector<Torus> &key_from, const SecretKey &key_to, ChaChaRng &rng) {  // :362-370
+    const SecurityParams &p = key_to.params;
+    return new_symmetric_with_params(key_from, key_to, p.alpha_lv0, p.basebit, p.iks_t, rng);
+  }
+  static ProxyReencryptionKey new_asymmetric_with_params(const std::vector<Torus> &key_from, const PublicKeyLv0 &public_key_to,
+                                                         double alpha, int basebit, int t, ChaChaRng &rng) {  // :294-330
+    return build(key_from, public_key_to.params, basebit, t, [&](double p) { return public_key_to.encrypt_f64(p, alpha, rng); });
+  }
+  static ProxyReencryptionKey new_asymmetric(const std::vector<Torus> &key_from, const PublicKeyLv0 &public_key_to, ChaChaRng &rng) {  // :271-279
+    const SecurityParams &p = public_key_to.params;
+    return new_asymmetric_with_params(key_from, public_key_to, p.alpha_lv0, p.basebit, p.iks_t, rng);
+  }
+
+  ProxyReencryptionKey() = default;
+  ProxyReencryptionKey(ProxyReencryptionKey &&o) noexcept { *this = std::move(o); }
+  ProxyReencryptionKey &operator=(ProxyReencryptionKey &&o) noexcept {
+    drop();
+    params = o.params;
+    key_encryptions = std::move(o.key_encryptions);
+    view_ = o.view_;
+    o.view_ = nullptr;
+    return *this;
+  }
+  ProxyReencryptionKey(const ProxyReencryptionKey &) = delete;
+  ProxyReencryptionKey &operator=(const ProxyReencryptionKey &) = delete;
+  ~ProxyReencryptionKey() { drop(); }
+
+  // reencrypt_tlwe_lv0 (:468-510) over a batch; the key is uploaded into a key view of the shared context on first use
+  std::vector<Ciphertext> reencrypt(const std::vector<Ciphertext> &cts, int device = 0) const {
+    Engine &e = Engine::for_params(params, device);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!view_) {
+        e.check(tfhe_hip_key_create(e.ctx(), &view_));
+        const int rc = tfhe_hip_load_reenc_key(view_, key_encryptions.data());
+        if (rc != TFHE_HIP_OK) {
+          const std::string msg = tfhe_hip_last_error(view_);
+          tfhe_hip_ctx_destroy(view_);
+          view_ = nullptr;
+          throw std::runtime_error("tfhe_hip: " + msg);
+        }
+      }
+    }
+    const size_t w = (size_t)params.n + 1;
+    std::vector<Torus> flat(cts.size() * w), out(cts.size() * w);
+    for (size_t c = 0; c < cts.size(); ++c) {
+      if (cts[c].p.size() != w) throw std::runtime_error("ciphertext dimension does not match the re-encryption key");
+      std::memcpy(&flat[c * w], cts[c].p.data(), w * sizeof(Torus));
+    }
+    if (tfhe_hip_batch_reencrypt(view_, flat.data(), out.data(), cts.size()) != TFHE_HIP_OK)
+      throw std::runtime_error(std::string("tfhe_hip: ") + tfhe_hip_last_error(view_));
+    std::vector<Ciphertext> res(cts.size(), Ciphertext(params.n));
+    for (size_t c = 0; c < cts.size(); ++c) std::memcpy(res[c].p.data(), &out[c * w], w * sizeof(Torus));
+    return res;
+  }
+
+ private:
+  template <class Enc>
+  static ProxyReencryptionKey build(const std::vector<Torus> &key_from, SecurityParams p, int basebit, int t, Enc &&enc) {
+    p.basebit = basebit;
+    p.iks_t = t;
+    ProxyReencryptionKey k;
+    k.params = p;
+    const size_t base = (size_t)1 << basebit, n = (size_t)p.n, w = n + 1;
+    if (key_from.size() != n) throw std::runtime_error("source key has another dimension than the target's parameter set");
+    k.key_encryptions.assign(n * (size_t)t * base * w, 0u);
+    for (size_t i = 0; i < n; ++i)
+      for (size_t j = 0; j < (size_t)t; ++j)
+        for (size_t kk = 1; kk < base; ++kk) {  // k = 0 contributes nothing (:311-313)
+          const double pt = (double)((Torus)kk * key_from[i]) / (double)(1u << ((j + 1) * (size_t)basebit));
+          const Ciphertext c = enc(pt);
+          std::memcpy(&k.key_encryptions[(base * (size_t)t * i + base * j + kk) * w], c.p.data(), w * sizeof(Torus));
+        }
+    return k;
+  }
+  void drop() {
+    if (view_) tfhe_hip_ctx_destroy(view_);
+    view_ = nullptr;
+  }
+  mutable tfhe_hip_ctx *view_ = nullptr;
+  mutable std::mutex mu_;
+};
+
+inline Ciphertext reencrypt_tlwe_lv0(const Ciphertext &ct_from, const ProxyReencryptionKey &reenc_key) {  // :468
+  return reenc_key.reencrypt({ct_from})[0];
+}
+}  // namespace proxy_reenc
+
 }  // namespace rs_tfhe

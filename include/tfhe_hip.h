@@ -292,6 +292,29 @@ int tfhe_hip_batch_sample_extract(tfhe_hip_ctx *ctx, const uint32_t *trlwe, int 
 int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_lv1,
                                        uint32_t *out, size_t count);
 
+/* ---- proxy re-encryption (the reference's feature `proxy-reenc`, src/proxy_reenc.rs; SURVEY 8(f) rank 4: "same
+ * digit-lookup kernel shape as keyswitch") -------------------------------------------------------------------------
+ * Replaces: proxy_reenc::reencrypt_tlwe_lv0 (src/proxy_reenc.rs:468-510) over a batch:
+ *   out.b = in.b;  for i < n, j < t:  k = ((in.a[i] + 2^(32-(1+basebit*t))) >> (32-(j+1)*basebit)) & (base-1);
+ *                                     k != 0: out -= key[base*t*i + base*j + k]          (all n+1 words, wrapping)
+ * i.e. trgsw::identity_key_switching with a source of n coefficients, and it runs on the same kernels (the source is
+ * padded to N coefficients whose digits are all zero).  A context -- or a key view of one (tfhe_hip_key_create), so that
+ * cloud keys and re-encryption keys stay resident side by side -- holds EITHER a cloud key OR a re-encryption key:
+ * loading one drops the other; the bootstrap entry points return TFHE_HIP_ENOKEY on a handle that holds a
+ * re-encryption key, and these return it on a handle that does not.
+ *   key [n][t][base][n+1] u32 = ProxyReencryptionKey::key_encryptions (src/proxy_reenc.rs:224-233; the k = 0 entries
+ *   are never read, as in the reference :311-313), with base = 2^basebit and t of the context's parameter set (the
+ *   reference's new_symmetric / new_asymmetric use params::trgsw_lv1::{BASEBIT, IKS_T}, :271-279, :362-370; for
+ *   *_with_params keys create the context with that basebit / t).  The key is generated by the client (it needs the
+ *   delegator's secret key): rs-tfhe_amd/proxy_reenc.py mirrors PublicKeyLv0 and ProxyReencryptionKey.
+ *   Needs n <= N = 1024 (every set but SECURITY_UINT5 .. 8): TFHE_HIP_EINVAL otherwise.
+ *   in [count][n+1] -> out [count][n+1]; the _dev form takes device pointers and a hipStream_t (NULL = the context's)
+ *   and only enqueues. */
+int tfhe_hip_load_reenc_key(tfhe_hip_ctx *ctx, const uint32_t *key);
+int tfhe_hip_reenc_key_is_loaded(tfhe_hip_ctx *ctx);
+int tfhe_hip_batch_reencrypt(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count);
+int tfhe_hip_batch_reencrypt_dev(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count, void *stream);
+
 /* Replaces: FFTProcessor::{ifft, fft, poly_mul, batch_ifft, batch_fft}
  * (src/fft/mod.rs:80-107; KlemsaProcessor src/fft/klemsa.rs:88-174) and the
  * SPQLIOS C ABI Spqlios_ifft_lv1 / _fft_lv1 / _poly_mul_1024

@@ -458,6 +458,60 @@ def batch_identity_key_switching(ck: CloudKey, cts_lv1) -> np.ndarray:
     return out
 
 
+# ----------------------------------------------------------------------------
+# proxy re-encryption: src/proxy_reenc.rs (feature `proxy-reenc`)
+# ----------------------------------------------------------------------------
+class PublicKeyLv0:
+    """proxy_reenc.rs:95-222: `size` encryptions of zero ([size][n+1]) and public-key encryption with them."""
+
+    def __init__(self, sk: SecretKey, seed: int, size: int = 0, alpha: float = None):
+        self.params = sk.params
+        size = 2 * sk.params.n if not size else int(size)  # :125-131
+        alpha = sk.params.alpha_lv0 if alpha is None else alpha
+        self.encryptions = np.empty((size, sk.params.n + 1), np.uint32)
+        lib().orc_gen_public_key_lv0(C.c_uint64(seed), _p(sk.key_lv0), sk.params.n, size, C.c_double(alpha), _p(self.encryptions))
+
+    def encrypt_f64(self, p, alpha: float, seed: int) -> np.ndarray:
+        p = _f64(np.atleast_1d(p))
+        out = np.empty((len(p), self.params.n + 1), np.uint32)
+        lib().orc_public_key_encrypt_f64_batch(C.c_uint64(seed), _p(self.encryptions), len(self.encryptions), self.params.n,
+                                                _p(p), len(p), C.c_double(alpha), _p(out))
+        return out
+
+    def encrypt_bool(self, bits, alpha: float, seed: int) -> np.ndarray:
+        bits = np.atleast_1d(np.asarray(bits)).astype(bool)
+        return self.encrypt_f64(np.where(bits, 0.125, -0.125), alpha, seed)
+
+
+def gen_reenc_key(params: Params, key_from, seed: int, key_to=None, public_key_to: PublicKeyLv0 = None,
+                  alpha: float = None) -> np.ndarray:
+    """ProxyReencryptionKey::new_symmetric[_with_params] (proxy_reenc.rs:362-425; pass key_to = the target level-0 key)
+    or ::new_asymmetric[_with_params] (:271-330; pass public_key_to).  Returns key_encryptions [n*t*base][n+1]; base
+    and t are the parameter set's."""
+    assert (key_to is None) != (public_key_to is None)
+    alpha = params.alpha_lv0 if alpha is None else alpha  # params::KSK_ALPHA (params.rs:468)
+    key = np.empty((params.n * params.t * params.base, params.n + 1), np.uint32)
+    cp = params.c()
+    kf = _u32(key_from)
+    if public_key_to is None:
+        kt = _u32(key_to)
+        lib().orc_gen_reenc_key(C.c_uint64(seed), C.byref(cp), _p(kf), _p(kt), None, 0, C.c_double(alpha), _p(key))
+    else:
+        pk = public_key_to.encryptions
+        lib().orc_gen_reenc_key(C.c_uint64(seed), C.byref(cp), _p(kf), None, _p(pk), len(pk), C.c_double(alpha), _p(key))
+    return key
+
+
+def reencrypt_tlwe_lv0(params: Params, key_encryptions, cts) -> np.ndarray:
+    """reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510) over [count][n+1]."""
+    cts = _u32(cts).reshape(-1, params.n + 1)
+    key = _u32(key_encryptions)
+    out = np.empty_like(cts)
+    cp = params.c()
+    lib().orc_batch_reencrypt(_p(cts), _p(key), C.byref(cp), _p(out), C.c_size_t(len(cts)))
+    return out
+
+
 def batch_gate(ck: CloudKey, op: int, a, b, nthreads: int = 0) -> np.ndarray:
     a = _u32(a).reshape(-1, ck.params.n + 1)
     bb = _u32(b).reshape(-1, ck.params.n + 1) if b is not None else None

@@ -900,6 +900,102 @@ void orc_lut_generate(const int *fvals, int message_modulus, uint32_t *testvec) 
   }
 }
 
+/* ------------------------------------------------------------------------- */
+/* Proxy re-encryption: src/proxy_reenc.rs (feature `proxy-reenc`)             */
+/* ------------------------------------------------------------------------- */
+/* PublicKeyLv0::new_with_params (proxy_reenc.rs:144-153): `size` encryptions of zero; pk [size][n+1] */
+void orc_gen_public_key_lv0(uint64_t seed, const uint32_t *key_lv0, int n, int size, double alpha,
+                            uint32_t *pk) {
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < size; c++) {
+    orc_rng r;
+    orc_rng_seed(&r, seed + 0xA24BAED4963EE407ull * (uint64_t)(c + 1));
+    tlwe_encrypt_f64_rng(&r, 0.0, alpha, key_lv0, n, pk + (size_t)c * (n + 1));
+  }
+}
+
+/* PublicKeyLv0::encrypt_f64 (proxy_reenc.rs:168-200): b = f64_to_torus(p); every encryption of zero joins with
+ * probability 1/2 (gen_bool(0.5), :178), added or subtracted with probability 1/2 (:180-188); fresh noise on b (:193-197) */
+static void public_key_encrypt_f64_rng(orc_rng *r, const uint32_t *pk, int size, int n, double p,
+                                       double alpha, uint32_t *out) {
+  memset(out, 0, (size_t)(n + 1) * sizeof(uint32_t));
+  out[n] = orc_f64_to_torus(p);
+  for (int e = 0; e < size; e++) {
+    const uint32_t *enc = pk + (size_t)e * (n + 1);
+    if (rng_next(r) >> 63) {
+      if (rng_next(r) >> 63) {
+        for (int i = 0; i <= n; i++) out[i] += enc[i];
+      } else {
+        for (int i = 0; i <= n; i++) out[i] -= enc[i];
+      }
+    }
+  }
+  out[n] += gaussian_f64(r, 0.0, alpha);
+}
+
+void orc_public_key_encrypt_f64_batch(uint64_t seed, const uint32_t *pk, int size, int n, const double *p,
+                                      int count, double alpha, uint32_t *out) {
+#pragma omp parallel for schedule(static)
+  for (int c = 0; c < count; c++) {
+    orc_rng r;
+    orc_rng_seed(&r, seed + 0x9FB21C651E98DF25ull * (uint64_t)(c + 1));
+    public_key_encrypt_f64_rng(&r, pk, size, n, p[c], alpha, out + (size_t)c * (n + 1));
+  }
+}
+
+/* ProxyReencryptionKey::new_symmetric_with_params (proxy_reenc.rs:389-425) when pk == NULL,
+ * ::new_asymmetric_with_params (:294-330) otherwise.  key [n][t][base][n+1], the k == 0 entries stay zero (:311-313) */
+void orc_gen_reenc_key(uint64_t seed, const orc_params *P, const uint32_t *key_from, const uint32_t *key_to,
+                       const uint32_t *pk, int pk_size, double alpha, uint32_t *key) {
+  const int base = 1 << P->basebit, n = P->n;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    orc_rng r;
+    orc_rng_seed(&r, seed ^ (0xD6E8FEB86659FD93ull * (uint64_t)(i + 1)));
+    for (int j = 0; j < P->t; j++) {
+      for (int k = 0; k < base; k++) {
+        size_t idx = ((size_t)base * P->t * i) + ((size_t)base * j) + k;
+        uint32_t *row = key + idx * (size_t)(n + 1);
+        if (k == 0) {
+          memset(row, 0, (size_t)(n + 1) * sizeof(uint32_t));
+          continue;
+        }
+        double p = (double)((uint32_t)k * key_from[i]) / (double)(1u << ((j + 1) * P->basebit));
+        if (pk)
+          public_key_encrypt_f64_rng(&r, pk, pk_size, n, p, alpha, row);
+        else
+          tlwe_encrypt_f64_rng(&r, p, alpha, key_to, n, row);
+      }
+    }
+  }
+}
+
+/* reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510): src [n+1]; key [n][t][base][n+1]; out [n+1] */
+void orc_reencrypt_tlwe_lv0(const uint32_t *src, const uint32_t *key, const orc_params *P, uint32_t *out) {
+  const int n = P->n, basebit = P->basebit, t = P->t;
+  const int base = 1 << basebit;
+  memset(out, 0, (size_t)(n + 1) * sizeof(uint32_t));
+  out[n] = src[n];
+  const uint32_t prec_offset = 1u << (32 - (1 + basebit * t));
+  for (int i = 0; i < n; i++) {
+    uint32_t a_bar = src[i] + prec_offset;
+    for (int j = 0; j < t; j++) {
+      uint32_t k = (a_bar >> (32 - (j + 1) * basebit)) & ((1u << basebit) - 1u);
+      if (k != 0) {
+        size_t idx = ((size_t)base * t * i) + ((size_t)base * j) + k;
+        const uint32_t *row = key + idx * (size_t)(n + 1);
+        for (int x = 0; x <= n; x++) out[x] -= row[x];
+      }
+    }
+  }
+}
+
+void orc_batch_reencrypt(const uint32_t *in, const uint32_t *key, const orc_params *P, uint32_t *out, size_t count) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (long c = 0; c < (long)count; c++)
+    orc_reencrypt_tlwe_lv0(in + (size_t)c * (P->n + 1), key, P, out + (size_t)c * (P->n + 1));
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

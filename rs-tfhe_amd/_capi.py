@@ -99,6 +99,10 @@ SIGNATURES = {
     "tfhe_hip_batch_external_product": (C.c_int, [_CTX, _P, _P, _P, _SZ]),
     "tfhe_hip_batch_sample_extract": (C.c_int, [_CTX, _P, C.c_int, _P, _SZ]),
     "tfhe_hip_batch_identity_key_switch": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_load_reenc_key": (C.c_int, [_CTX, _P]),
+    "tfhe_hip_reenc_key_is_loaded": (C.c_int, [_CTX]),
+    "tfhe_hip_batch_reencrypt": (C.c_int, [_CTX, _P, _P, _SZ]),
+    "tfhe_hip_batch_reencrypt_dev": (C.c_int, [_CTX, _P, _P, _SZ, _P]),
     "tfhe_hip_batch_ifft": (C.c_int, [_CTX, _P, _P, _SZ]),
     "tfhe_hip_batch_fft": (C.c_int, [_CTX, _P, _P, _SZ]),
     "tfhe_hip_batch_poly_mul": (C.c_int, [_CTX, _P, _P, _P, _SZ]),

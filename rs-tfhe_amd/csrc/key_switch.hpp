@@ -642,4 +642,14 @@ __global__ void k_ksk_convert(const uint32_t *__restrict__ ref, uint32_t *__rest
   for (int x = threadIdx.x; x < rw; x += blockDim.x) dst[x] = (zero || x > n) ? 0u : src[x];
 }
 
+// Proxy re-encryption (proxy_reenc.rs:468-510) is the identity key switch with a source of n coefficients instead of N
+// and rides on the kernels above: a level-0 sample [n+1] becomes a level-1 shaped row [N+1] whose coefficients n .. N-1
+// are 0 -- a_bar = prec_offset there, every digit 0, no row subtracted (trgsw.rs:343-351) -- with its body word at N.
+__global__ __launch_bounds__(256) void k_reenc_pad(const uint32_t *__restrict__ in, uint32_t *__restrict__ lv1, int n) {
+  constexpr int N = 1024;
+  const uint32_t *src = in + (size_t)blockIdx.x * (size_t)(n + 1);
+  uint32_t *dst = lv1 + (size_t)blockIdx.x * (size_t)(N + 1);
+  for (int i = threadIdx.x; i <= N; i += 256) dst[i] = i < n ? src[i] : (i == N ? src[n] : 0u);
+}
+
 }  // namespace tfhe

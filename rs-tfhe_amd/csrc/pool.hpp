@@ -70,7 +70,7 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   const tfhe_hip_params &P = ctx->P;
   const size_t bsk_bytes = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
   const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
-  ctx->K->key_loaded = false;
+  ctx->K->key_loaded = ctx->K->reenc_loaded = false;
   if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, bsk_bytes));
   if (!ctx->K->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, ksk_bytes + 4096));
   if (!ctx->K->d_testvec) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_testvec, 2 * kN * 4));
@@ -169,7 +169,7 @@ int prepare_replica(tfhe_hip_ctx *member) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
   const tfhe_hip_params &P = ctx->P;
-  ctx->K->key_loaded = false;
+  ctx->K->key_loaded = ctx->K->reenc_loaded = false;
   if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double)));
   if (!ctx->K->d_ksk)
     HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4 + 4096));

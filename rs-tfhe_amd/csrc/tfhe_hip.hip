@@ -99,6 +99,7 @@ struct KeyState {
   uint32_t *d_testvec = nullptr;
   uint32_t offset = 0;
   bool key_loaded = false;
+  bool reenc_loaded = false;  // d_ksk (+ d_ksk8) hold a proxy re-encryption key (proxy_reenc.rs:224-233) instead of a cloud key's
 };
 
 struct tfhe_hip_ctx {
@@ -745,6 +746,11 @@ int need_key(tfhe_hip_ctx *ctx) {
   return TFHE_HIP_OK;
 }
 
+int need_reenc_key(tfhe_hip_ctx *ctx) {
+  if (!ctx->K->reenc_loaded) return fail(ctx, TFHE_HIP_ENOKEY, "re-encryption key not loaded");
+  return TFHE_HIP_OK;
+}
+
 hipStream_t pick(tfhe_hip_ctx *ctx, void *stream) { return stream ? (hipStream_t)stream : ctx->stream; }
 
 // The intermediate buffers (lv1, u1, u2) belong to the context, not to a call.  Work queued on one
@@ -775,6 +781,16 @@ int gates_mixed_dev(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, 
   CHK(claim_scratch(ctx, s));
   CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
   CHK(launch_blind_rotate(ctx, s, a, b, gp, nullptr, 0, count, nullptr, (uint32_t *)ctx->lv1.p, nullptr, gates));
+  return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
+}
+
+// proxy_reenc::reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510): pad to the key switch's source shape, then the key switch
+int reencrypt_dev(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count, hipStream_t s) {
+  if (count == 0) return TFHE_HIP_OK;
+  CHK(claim_scratch(ctx, s));
+  CHK(ensure(ctx, ctx->lv1, lv1_rows(count) * (size_t)(kN + 1) * 4));
+  hipLaunchKernelGGL(k_reenc_pad, dim3((unsigned)count), dim3(256), 0, s, in, (uint32_t *)ctx->lv1.p, ctx->P.n);
+  HIPCHK(ctx, hipGetLastError());
   return launch_key_switch(ctx, s, (const uint32_t *)ctx->lv1.p, out, count);
 }
 
@@ -1204,7 +1220,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   const size_t bsk_bytes = polys * kN * sizeof(double);
   const int base = 1 << P.basebit;
   const size_t ksk_words = (size_t)kN * P.t * base * (size_t)(P.n + 1);
-  ctx->K->key_loaded = false;
+  ctx->K->key_loaded = ctx->K->reenc_loaded = false;
   if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, bsk_bytes));
   if (!ctx->K->d_ksk)
     HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
@@ -1256,7 +1272,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   const tfhe_hip_params &P = ctx->P;
   const int base = 1 << P.basebit;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
-  ctx->K->key_loaded = false;
+  ctx->K->key_loaded = ctx->K->reenc_loaded = false;
   if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, polys * kN * sizeof(double)));
   if (!ctx->K->d_ksk)
     HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, (size_t)kN * P.t * base * ksk_row_words(P.n) * 4 + 4096));
@@ -1425,6 +1441,7 @@ int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = decomp_offset;
   ctx->K->key_loaded = true;
+  ctx->K->reenc_loaded = false;
   return TFHE_HIP_OK;
 }
 
@@ -1754,6 +1771,67 @@ int tfhe_hip_batch_identity_key_switch(tfhe_hip_ctx *ctx, const uint32_t *tlwe_l
   CHK(ensure(ctx, ctx->h_out, obytes));
   CHK(launch_key_switch(ctx, ctx->stream, (const uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_out.p, count));
   return to_host(ctx, out, ctx->h_out, obytes);
+}
+
+// ---- proxy re-encryption (src/proxy_reenc.rs; feature `proxy-reenc` of the reference) -------------------------------
+// key [n][t][base][n+1]: ProxyReencryptionKey::key_encryptions (proxy_reenc.rs:224-233, index base*t*i + base*j + k).
+// It is stored as a key-switching key whose coefficients n .. N-1 have all-zero rows (never selected: k_reenc_pad).
+int tfhe_hip_load_reenc_key(tfhe_hip_ctx *ctx, const uint32_t *key) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  if (!key) return fail(ctx, TFHE_HIP_EINVAL, "null key pointer");
+  const tfhe_hip_params &P = ctx->P;
+  // the source rides in the key switch's N-coefficient rows (k_reenc_pad): SECURITY_UINT5 .. 8 (n = 1071 / 1160) do not fit
+  if (P.n > kN) return fail(ctx, TFHE_HIP_EINVAL, "proxy re-encryption needs n <= N = 1024 (this parameter set's n is larger)");
+  if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->scratch_owned = false;
+  const int base = 1 << P.basebit;
+  const size_t eng_bytes = (size_t)kN * P.t * base * ksk_row_words(P.n) * 4;
+  const size_t rows = (size_t)P.n * P.t * base, words = rows * (size_t)(P.n + 1);
+  ctx->K->key_loaded = ctx->K->reenc_loaded = false;  // the buffer is shared with a cloud key's key-switching key
+  if (!ctx->K->d_ksk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_ksk, eng_bytes + 4096));
+  uint32_t *d_ref = nullptr;
+  HIPCHK(ctx, hipMalloc((void **)&d_ref, words * 4));
+  hipError_t e = hipMemsetAsync(ctx->K->d_ksk, 0, eng_bytes, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_ref, key, words * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_ksk_convert, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_ref, ctx->K->d_ksk, P.n, base, rows);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(d_ref);
+  if (e != hipSuccess) return fail(ctx, TFHE_HIP_EHIP, std::string("re-encryption key upload: ") + hipGetErrorString(e));
+  CHK(build_ksk_planes(ctx));
+  ctx->K->reenc_loaded = true;
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_reenc_key_is_loaded(tfhe_hip_ctx *ctx) {
+  if (!ctx) return 0;
+  ENTER(ctx);
+  return ctx->K->reenc_loaded ? 1 : 0;
+}
+
+int tfhe_hip_batch_reencrypt_dev(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count, void *stream) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  CHK(need_reenc_key(ctx));
+  if (count && (!in || !out)) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  return reencrypt_dev(ctx, in, out, count, pick(ctx, stream));
+}
+
+int tfhe_hip_batch_reencrypt(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  ENTER(ctx);
+  CHK(need_reenc_key(ctx));
+  if (count == 0) return TFHE_HIP_OK;
+  if (!in || !out) return fail(ctx, TFHE_HIP_EINVAL, "null pointer");
+  const size_t bytes = count * (size_t)(ctx->P.n + 1) * 4;
+  CHK(to_dev(ctx, ctx->h_a, in, bytes));
+  CHK(ensure(ctx, ctx->h_out, bytes));
+  CHK(reencrypt_dev(ctx, (const uint32_t *)ctx->h_a.p, (uint32_t *)ctx->h_out.p, count, ctx->stream));
+  return to_host(ctx, out, ctx->h_out, bytes);
 }
 
 int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, size_t count) {

@@ -358,6 +358,31 @@ class Engine:
         self._chk(self._lib.tfhe_hip_batch_identity_key_switch(self._ctx, _ptr(lv1), _ptr(out), len(lv1)))
         return out
 
+    # -- proxy re-encryption (src/proxy_reenc.rs; rs-tfhe_amd/proxy_reenc.py holds the client side) --------
+    def load_reenc_key(self, key_encryptions) -> None:
+        """ProxyReencryptionKey::key_encryptions [n][t][base][n+1] (proxy_reenc.rs:224-233) -> this handle (a context
+        or a key view holds EITHER a cloud key OR a re-encryption key: `tfhe_hip_load_reenc_key`)."""
+        p = self.params
+        key = _u32(key_encryptions)
+        if key.size != p.n * p.iks_t * p.base * (p.n + 1):
+            raise ValueError("re-encryption key has the wrong size for these parameters")
+        self._chk(self._lib.tfhe_hip_load_reenc_key(self._ctx, _ptr(key)))
+
+    def reenc_key_is_loaded(self) -> bool:
+        return bool(self._lib.tfhe_hip_reenc_key_is_loaded(self._ctx))
+
+    def batch_reencrypt(self, cts) -> np.ndarray:
+        """proxy_reenc::reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510) over [count][n+1] host ciphertexts."""
+        cts = _u32(cts).reshape(-1, self.params.n + 1)
+        out = np.empty_like(cts)
+        self._chk(self._lib.tfhe_hip_batch_reencrypt(self._ctx, _ptr(cts), _ptr(out), len(cts)))
+        return out
+
+    def batch_reencrypt_dev(self, a, out, stream=None) -> None:
+        """The same on int32 CUDA tensors [count][n+1] of this engine's GPU; only enqueues."""
+        count = self._dev_batch(a, out)
+        self._chk(self._lib.tfhe_hip_batch_reencrypt_dev(self._ctx, self._tp(a), self._tp(out), count, self._stream_ptr(stream)))
+
     def batch_ifft(self, polys) -> np.ndarray:
         polys = _u32(polys).reshape(-1, N)
         out = np.empty((len(polys), N), np.float64)

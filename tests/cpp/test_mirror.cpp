@@ -23,6 +23,7 @@ void orc_gen_key_switching_key(uint64_t seed, const orc_params *P, const uint32_
 void orc_tlwe_encrypt_f64(uint64_t seed, double p, double alpha, const uint32_t *key, int dim, uint32_t *out);
 int orc_tlwe_decrypt_bool(const uint32_t *ct, const uint32_t *key, int dim);
 int orc_tlwe_decrypt_lwe_message(const uint32_t *ct, int m, const uint32_t *key, int dim);
+void orc_reencrypt_tlwe_lv0(const uint32_t *src, const uint32_t *key, const orc_params *P, uint32_t *out);
 // the four HIP runtime calls the device-resident pool test needs (libamdhip64 is linked; no HIP headers under g++)
 int hipMalloc(void **p, size_t bytes);
 int hipFree(void *p);
@@ -210,6 +211,42 @@ int main() {
       LutBootstrap lb;
       Ciphertext r = lb.bootstrap_lut(x + y, gen.generate_lookup_table([](size_t v) { return (v + 1) % 4; }), gk);
       CHECK(tlwe::decrypt_lwe_message(r, 4, sk.key_lv0) == 0, "bootstrap_lut(x + y)");
+    }
+    // proxy re-encryption through the header alone (src/proxy_reenc.rs): Alice -> Bob symmetric, and through Bob's
+    // public key; the GPU's words equal reencrypt_tlwe_lv0 (:468-510) of the oracle on the same key
+    {
+      rs_tfhe::SecretKey bob = rs_tfhe::SecretKey::generate(P, 4343);
+      ChaChaRng prng(6);
+      proxy_reenc::ProxyReencryptionKey rk = proxy_reenc::ProxyReencryptionKey::new_symmetric(sk.key_lv0, bob, prng);
+      CHECK(rk.key_encryptions.size() == (size_t)P.n * P.iks_t * P.base() * (P.n + 1), "re-encryption key size (proxy_reenc.rs:645-649)");
+      std::vector<Ciphertext> cts;
+      std::vector<bool> msg;
+      for (int i = 0; i < 70; ++i) {
+        msg.push_back((prng() & 1u) != 0);
+        cts.push_back(tlwe::encrypt_bool(msg.back(), P.alpha_lv0, sk.key_lv0, prng));
+      }
+      std::vector<Ciphertext> got = rk.reencrypt(cts);
+      int ok = 0, same = 0;
+      for (size_t i = 0; i < cts.size(); ++i) {
+        ok += tlwe::decrypt_bool(got[i], bob.key_lv0) == msg[i];
+        Ciphertext want(P.n);
+        orc_reencrypt_tlwe_lv0(cts[i].p.data(), rk.key_encryptions.data(), &OP, want.p.data());
+        same += want.p == got[i].p;
+      }
+      CHECK(ok == (int)cts.size(), "symmetric re-encryption decrypts under the target key: %d of %zu", ok, cts.size());
+      CHECK(same == (int)cts.size(), "re-encryption bit-identical to the oracle: %d of %zu", same, cts.size());
+      CHECK(proxy_reenc::reencrypt_tlwe_lv0(cts[3], rk).p == got[3].p, "single-ciphertext form");
+      proxy_reenc::PublicKeyLv0 pub = proxy_reenc::PublicKeyLv0::generate(bob, prng);
+      CHECK(pub.encryptions.size() == (size_t)2 * P.n, "public key: 2n encryptions of zero");
+      int pk_ok = 0;
+      for (int i = 0; i < 40; ++i) pk_ok += tlwe::decrypt_bool(pub.encrypt_bool(i & 1, P.alpha_lv0, prng), bob.key_lv0) == (bool)(i & 1);
+      CHECK(pk_ok > 36, "public-key encryption decrypts (> 90 %%, the reference's bar): %d of 40", pk_ok);
+      proxy_reenc::ProxyReencryptionKey ak = proxy_reenc::ProxyReencryptionKey::new_asymmetric(sk.key_lv0, pub, prng);
+      std::vector<Ciphertext> agot = ak.reencrypt(cts);
+      int aok = 0;
+      for (size_t i = 0; i < cts.size(); ++i) aok += tlwe::decrypt_bool(agot[i], bob.key_lv0) == msg[i];
+      CHECK(aok * 10 > (int)cts.size() * 9, "asymmetric re-encryption (> 90 %%, proxy_reenc.rs:627-632): %d of %zu", aok, cts.size());
+      lap("proxy re-encryption");
     }
     // a different key object at the same address must not be mistaken for the loaded one
     CloudKey *slot = new CloudKey(gk);
