@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--resident", action="store_true", help="with --pool-devices: the batch is RESIDENT on the first device's "
                     "GPU and goes through tfhe_hip_pool_batch_*_dev (shards scattered / gathered between the members by grouped "
                     "RCCL send / receive, or peer copies when a device repeats); prints scatter_ms / gather_ms")
-    ap.add_argument("--stage", default=None, choices=["blind_rotate", "ifft", "fft", "poly_mul"],
+    ap.add_argument("--stage", default=None, choices=["blind_rotate", "ifft", "fft", "poly_mul", "reencrypt"],
                     help="time one stage entry point instead of the gate path: the reference's criterion groups "
                     "`bootstrapping` (= trgsw::blind_rotate) and `fft_operations` (benches/gate_benchmarks.rs:77-125)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU sample (whole thread sweep)")
@@ -111,6 +111,29 @@ def stage_mode(args):
                     "value": round(B / whole, 1), "unit": "blind rotations/s",
                     "kernel_ms_per_launch": round(kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"]), 3),
                     "dispatch": eng.describe_dispatch(B), "device_resident": True})
+    elif args.stage == "reencrypt":
+        # proxy_reenc::reencrypt_tlwe_lv0 (src/proxy_reenc.rs:468-510; the reference has no criterion bench for it): one
+        # ciphertext, and a device-resident batch -- one launch of the key-switch kernels (+ the padding kernel)
+        from rs_tfhe_amd import proxy_reenc as PR
+
+        alice, bob = R.SecretKey.new(P, seed=2024), R.SecretKey.new(P, seed=2026)
+        rk = PR.ProxyReencryptionKey.new_symmetric(alice, bob, seed=2027)
+        eng.load_reenc_key(rk.key_encryptions)
+        B = args.batch
+        bits = rng.integers(0, 2, B).astype(bool)
+        cts = alice.encrypt_bool(bits, seed=5)
+        tin = torch.from_numpy(cts.view(np.int32)).to("cuda:0")
+        tout = torch.empty_like(tin)
+        one = timed(lambda: eng.batch_reencrypt(cts[:1]), max(20, args.steps))
+        eng.set_profiling(True)
+        whole = timed(lambda: eng.batch_reencrypt_dev(tin, tout), args.steps)
+        kt = eng.kernel_times()
+        ok = bool(np.array_equal(bob.decrypt_bool(tout.cpu().numpy().view(np.uint32)), bits))
+        res.update({"reference_bench": "proxy_reenc::reencrypt_tlwe_lv0, src/proxy_reenc.rs:468-510 (no criterion bench in the reference)",
+                    "single_call_ms": round(one * 1e3, 4), "batch": B, "batch_ms": round(whole * 1e3, 3),
+                    "value": round(B / whole, 1), "unit": "re-encryptions/s",
+                    "kernel_ms_per_launch": round(kt["key_switch_ms"] / max(1, kt["key_switch_launches"]), 3),
+                    "dispatch": eng.describe_dispatch(B).split(" ", 1)[1], "device_resident": True, "decrypt_ok": ok})
     else:
         B = min(args.batch, 16384)
         polys = rng.integers(0, 2**32, (B, N), dtype=np.uint64).astype(np.uint32)

@@ -19,5 +19,5 @@ python3 bench.py --pool-devices 0 --steps 5 --warmup 2 2>/dev/null | grep '^{' >
 python3 bench.py --pool-devices 0 --pinned --steps 5 --warmup 2 2>/dev/null | grep '^{' > gpurun_out/r4_pool_host_pinned.json
 # the reference's criterion groups `bootstrapping` and `fft_operations`
 : > gpurun_out/r4_stage_bench.jsonl
-for st in blind_rotate ifft fft poly_mul; do python3 bench.py --stage $st --steps 5 --warmup 2 2>/dev/null | grep '^{' >> gpurun_out/r4_stage_bench.jsonl; done
+for st in blind_rotate ifft fft poly_mul reencrypt; do python3 bench.py --stage $st --steps 5 --warmup 2 2>/dev/null | grep '^{' >> gpurun_out/r4_stage_bench.jsonl; done
 head -c 300 gpurun_out/r4_bench.json
