@@ -259,7 +259,8 @@ def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
     one-hot contraction (2 x ciphertexts x 4*N*t rows x padded output columns x 4 byte planes) against the guide's
     measured i8 ceiling (3,944 TOPS, v_mfma_i32_16x16x64_i8; 32x32x32: 4,404), with the clock the kernel sustained
     (the matrix pipes are current-limited: 1.6-2.4 GHz depending on operand toggling,
-    profiles/exp/logs/r3d_ubench_mfma.log).  Other sets: the LDS-ring kernels, instruction-issue bound."""
+    profiles/exp/logs/r3d_ubench_mfma.log).  Wider bases: the column-sliced kernel against the CUs' LDS read bandwidth.
+    Anything else (forced fallback kernels): instruction-issue bound."""
     mfma = "key_switch=mfma" in plan  # what the library says it launched (tfhe_hip_describe_dispatch)
     out = {"avg_launch_ms": round(ks_ms, 3), "kernel": "k_key_switch_" + plan.split("key_switch=")[-1].split("(")[0] if plan else None}
     if mfma and ks_ms > 0:
@@ -273,6 +274,16 @@ def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
             # the same ops against what the pipes deliver at the clock they were allowed: 1,024 SIMDs x 2,048 ops/clk
             "frac_at_sustained_clock": round(tops * 1e12 / (1024 * 2048 * mhz * 1e6), 4) if mhz else None,
         })
+    elif "key_switch=sliced" in plan and ks_ms > 0:
+        # column-sliced kernel (bases 16 .. 128): every ciphertext reads one 256-byte row slice per (group, 64-column
+        # slice) from the LDS ring -- N*t groups x ceil((n+1)/64) slices -- which is what binds it since the round-4
+        # rewrite (profiles/exp/logs/r4_ks_sl_ablation.log); peak: ds_read_b128 at 256 B/clk per CU, 256 CUs, 2.4 GHz
+        lds_bytes = float(per_launch) * 1024 * P.iks_t * (-(-(P.n + 1) // 64)) * 256
+        tbps = lds_bytes / (ks_ms * 1e-3) / 1e12
+        peak = 256 * 256 * 2.4e9 / 1e12
+        out.update({"bound": "lds_read", "achieved": round(tbps, 1), "peak": round(peak, 1), "unit": "TB/s (LDS)",
+                    "frac": round(tbps / peak, 4), "lds_bytes_per_launch": lds_bytes,
+                    "issue_frac": pm.get("key_switch", {}).get("issue_frac")})
     else:
         out.update({"bound": "valu+salu issue", "issue_frac": pm.get("key_switch", {}).get("issue_frac")})
     out["algorithmic_hbm_GBps"] = round(P.ksk_touched_bytes * per_launch / (ks_ms * 1e-3) / 1e9, 1) if ks_ms > 0 else None
