@@ -264,10 +264,10 @@ __global__ __launch_bounds__(64 * kL1Waves, 3) void k_blind_rotate_l1(BlindRotat
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
       const int j = lane + 64 * m;
-      acc_add(&acc[j], round_to_torus<FAST>(fa_re[m]));
-      acc_add(&acc[j + kN2], round_to_torus<FAST>(fa_im[m]));
-      acc_add(&acc[kN + j], round_to_torus<FAST>(fb_re[m]));
-      acc_add(&acc[kN + j + kN2], round_to_torus<FAST>(fb_im[m]));
+      acc_add(&acc[j], round_product<FAST>(fa_re[m]));
+      acc_add(&acc[j + kN2], round_product<FAST>(fa_im[m]));
+      acc_add(&acc[kN + j], round_product<FAST>(fb_re[m]));
+      acc_add(&acc[kN + j + kN2], round_product<FAST>(fb_im[m]));
     }
     // lgkmcnt(0): the accumulator is final for this step (the next one re-reads it at other lanes' positions) AND the two
     // scalar loads have returned; their registers pass through the statement so that nothing reads them above it

@@ -185,8 +185,8 @@ __global__ __launch_bounds__(128 * L, 1) void k_blind_rotate_wide(BlindRotateArg
           if (m == 0 && f_re[0] + f_im[7] == 1.2345) q[j] = 1u;
           continue;
         }
-        acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
-        acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
+        acc_add(&q[j], round_product<FAST>(f_re[m]));
+        acc_add(&q[j + kN2], round_product<FAST>(f_im[m]));
       }
     }
     LAT_STAMP(7);

@@ -361,25 +361,25 @@ __global__ __launch_bounds__(64 * kBrWaves, 2) void k_blind_rotate(BlindRotateAr
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
       const int j = lane + 64 * m;
-      acc_add(&acc[j], round_to_torus<FAST>(fa_re[m]));
-      acc_add(&acc[j + kN2], round_to_torus<FAST>(fa_im[m]));
-      acc_add(&acc[kN + j], round_to_torus<FAST>(fb_re[m]));
-      acc_add(&acc[kN + j + kN2], round_to_torus<FAST>(fb_im[m]));
+      acc_add(&acc[j], round_product<FAST>(fa_re[m]));
+      acc_add(&acc[j + kN2], round_product<FAST>(fa_im[m]));
+      acc_add(&acc[kN + j], round_product<FAST>(fb_re[m]));
+      acc_add(&acc[kN + j + kN2], round_product<FAST>(fb_im[m]));
     }
 #else
     fft_inverse(fa_re, fa_im, tw, tile, lane);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
       const int j = lane + 64 * m;
-      acc[j] += round_to_torus<FAST>(fa_re[m]);
-      acc[j + kN2] += round_to_torus<FAST>(fa_im[m]);
+      acc[j] += round_product<FAST>(fa_re[m]);
+      acc[j + kN2] += round_product<FAST>(fa_im[m]);
     }
     fft_inverse(fb_re, fb_im, tw, tile, lane);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int j = lane + 64 * m;
-      acc[kN + j] += round_to_torus<FAST>(fb_re[m]);
-      acc[kN + j + kN2] += round_to_torus<FAST>(fb_im[m]);
+      acc[kN + j] += round_product<FAST>(fb_re[m]);
+      acc[kN + j + kN2] += round_product<FAST>(fb_im[m]);
     }
 #endif
     wave_lds_sync();  // the next step re-reads acc at rotated (other lanes') positions
@@ -475,14 +475,14 @@ __global__ __launch_bounds__(64) void k_external_product(const uint32_t *in, con
   fft_inverse(fa_re, fa_im, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    o[lane + 64 * m] = round_to_torus<FAST>(fa_re[m]);
-    o[lane + 64 * m + kN2] = round_to_torus<FAST>(fa_im[m]);
+    o[lane + 64 * m] = round_product<FAST>(fa_re[m]);
+    o[lane + 64 * m + kN2] = round_product<FAST>(fa_im[m]);
   }
   fft_inverse(fb_re, fb_im, tw, tile, lane);
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
-    o[kN + lane + 64 * m] = round_to_torus<FAST>(fb_re[m]);
-    o[kN + lane + 64 * m + kN2] = round_to_torus<FAST>(fb_im[m]);
+    o[kN + lane + 64 * m] = round_product<FAST>(fb_re[m]);
+    o[kN + lane + 64 * m + kN2] = round_product<FAST>(fb_im[m]);
   }
 }
 
@@ -583,13 +583,13 @@ __global__ void k_sample_extract(const uint32_t *trlwe, int k, uint32_t *out, si
 }
 
 // engine-order conversion of the bootstrapping key (upload time)
-__global__ void k_bsk_convert(const double *ref, double2 *eng, size_t polys) {
+__global__ void k_bsk_convert(const double *ref, double2 *eng, size_t polys, double scale /* key_scale(fast) */) {
   // one block per polynomial spectrum (i, r, c); 512 threads
   size_t p = blockIdx.x;
   int t = threadIdx.x;  // engine position s*64 + mu
   int s = t >> 6, mu = t & 63;
   int k = bin_of(mu, s);
-  eng[p * kN2 + t] = make_double2(ref[p * kN + k] * 0x1p-10, ref[p * kN + k + kN2] * 0x1p-10);
+  eng[p * kN2 + t] = make_double2(ref[p * kN + k] * scale, ref[p * kN + k + kN2] * scale);
 }
 
 }  // namespace tfhe

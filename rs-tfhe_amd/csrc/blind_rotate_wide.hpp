@@ -192,8 +192,8 @@ __global__ __launch_bounds__(64 * kWide2Waves, 1) void k_blind_rotate_wide2(Blin
 #pragma unroll
       for (int m = 0; m < 8; ++m) {  // res = ext + in1 (trgsw.rs:189-193)
         const int j = lane + 64 * m;
-        acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
-        acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
+        acc_add(&q[j], round_product<FAST>(f_re[m]));
+        acc_add(&q[j + kN2], round_product<FAST>(f_im[m]));
       }
     } else {
       load_next_keys();  // the six waves without an inverse transform: AFTER the barrier, so that nobody waits for the issue
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(64 * kPairWaves, 1) void k_blind_rotate_pair(BlindR
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int j = lane + 64 * m;
-      acc_add(&q[j], round_to_torus<FAST>(f_re[m]));
-      acc_add(&q[j + kN2], round_to_torus<FAST>(f_im[m]));
+      acc_add(&q[j], round_product<FAST>(f_re[m]));
+      acc_add(&q[j + kN2], round_product<FAST>(f_im[m]));
     }
   };
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_gen_ksk(const uint32_t *__restrict__ ke
 // One wave per TRLWE row (i, r) of TRGSW(s0[i]) (trgsw.rs:29-49):
 //   a uniform, b = gaussian(0) + a (*) s1        (trlwe.rs:30-52, product via the FFT as poly_mul does)
 //   r <  l: a[0] += s0[i] * f64_to_torus(Bg^-(r+1));  r >= l: b[0] += ... (trgsw.rs:44-47)
-//   spectrum of a and b (TRGSWLv1FFT::new, trgsw.rs:58-68) written in engine order, scaled 2^-10.
+//   spectrum of a and b (TRGSWLv1FFT::new, trgsw.rs:58-68) written in engine order with the engine's key scale (key_scale, fft512.hpp).
 // s1_spec: forward spectrum of the level-1 key in the forward-FFT bin order (k_key_spectrum).
 __global__ __launch_bounds__(64) void k_key_spectrum(const uint32_t *__restrict__ key_lv1, const double2 *__restrict__ twt,
                                                       double2 *__restrict__ s1_spec) {
@@ -149,7 +149,8 @@ __global__ __launch_bounds__(64) void k_key_spectrum(const uint32_t *__restrict_
 template <int L>
 __global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key_lv0, const double2 *__restrict__ s1_spec,
                                                  const double2 *__restrict__ twt, double2 *__restrict__ bsk_eng,
-                                                 int bgbit, double alpha, const ChaChaKey *__restrict__ key_p) {
+                                                 int bgbit, double alpha, const ChaChaKey *__restrict__ key_p,
+                                                 double scale /* key_scale(fast) */) {
   const ChaChaKey key = *key_p;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double2 *tile = reinterpret_cast<double2 *>(smem);
@@ -238,21 +239,22 @@ __global__ __launch_bounds__(64) void k_gen_bsk(const uint32_t *__restrict__ key
   double2 *dst = bsk_eng + (size_t)row * 2 * kN2;
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    // reference stores 2*DFT (klemsa.rs:112-113); engine folds 2^-10 on top: 2 * 2^-10 = 2^-9
-    dst[s * 64 + lane] = make_double2(are[s] * 0x1p-9, aim[s] * 0x1p-9);
-    dst[kN2 + s * 64 + lane] = make_double2(re[s] * 0x1p-9, im[s] * 0x1p-9);
+    // reference stores 2*DFT (klemsa.rs:112-113); engine folds its key scale (2^-10 or 2^-42, fft512.hpp) on top
+    const double k2 = 2.0 * scale;
+    dst[s * 64 + lane] = make_double2(are[s] * k2, aim[s] * k2);
+    dst[kN2 + s * 64 + lane] = make_double2(re[s] * k2, im[s] * k2);
   }
 }
 
 // ---- export: engine layouts back to the reference layouts (tests, key persistence) -------
-__global__ void k_bsk_export(const double2 *__restrict__ eng, double *__restrict__ ref, size_t polys) {
+__global__ void k_bsk_export(const double2 *__restrict__ eng, double *__restrict__ ref, size_t polys, double unscale /* 1 / key_scale(fast) */) {
   size_t p = blockIdx.x;
   int t = threadIdx.x;  // engine position s*64 + mu
   int s = t >> 6, mu = t & 63;
   int k = bin_of(mu, s);
   double2 v = eng[p * kN2 + t];
-  ref[p * kN + k] = v.x * 0x1p10;
-  ref[p * kN + k + kN2] = v.y * 0x1p10;
+  ref[p * kN + k] = v.x * unscale;
+  ref[p * kN + k + kN2] = v.y * unscale;
 }
 
 __global__ void k_ksk_export(const uint32_t *__restrict__ eng, uint32_t *__restrict__ ref, int n, size_t rows) {

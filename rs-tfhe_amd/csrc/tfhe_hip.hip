@@ -1230,7 +1230,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   HIPCHK(ctx, hipMalloc((void **)&d_ref, bsk_bytes));
   hipError_t e = hipMemcpyAsync(d_ref, bsk, bsk_bytes, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(k_bsk_convert, dim3((unsigned)polys), dim3(512), 0, ctx->stream, d_ref, ctx->K->d_bsk, polys);
+    hipLaunchKernelGGL(k_bsk_convert, dim3((unsigned)polys), dim3(512), 0, ctx->stream, d_ref, ctx->K->d_bsk, polys, key_scale(ctx->fast_round));
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1302,9 +1302,9 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   const ChaChaKey *d_rk = (const ChaChaKey *)ctx->h_idx.p;
   const dim3 bgrid((unsigned)(P.n * 2 * P.l));
   switch (P.l) {
-    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
-    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
-    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk); break;
+    case 1: hipLaunchKernelGGL(k_gen_bsk<1>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk, key_scale(ctx->fast_round)); break;
+    case 2: hipLaunchKernelGGL(k_gen_bsk<2>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk, key_scale(ctx->fast_round)); break;
+    default: hipLaunchKernelGGL(k_gen_bsk<3>, bgrid, dim3(64), kStageLdsBytes, ctx->stream, d_k0, d_spec, ctx->d_tw, ctx->K->d_bsk, P.bgbit, alpha_bsk, d_rk, key_scale(ctx->fast_round)); break;
   }
   HIPCHK(ctx, hipGetLastError());
   hipLaunchKernelGGL(k_gen_ksk, dim3((unsigned)((size_t)kN * P.t * base)), dim3(256), 0, ctx->stream, d_k0, d_k1,
@@ -1392,7 +1392,7 @@ int tfhe_hip_export_cloud_key(tfhe_hip_ctx *ctx, double *bsk, uint32_t *ksk, uin
   if (bsk) {
     const size_t polys = (size_t)P.n * 2 * P.l * 2;
     CHK(ensure(ctx, ctx->h_out, polys * kN * sizeof(double)));
-    hipLaunchKernelGGL(k_bsk_export, dim3((unsigned)polys), dim3(512), 0, ctx->stream, ctx->K->d_bsk, (double *)ctx->h_out.p, polys);
+    hipLaunchKernelGGL(k_bsk_export, dim3((unsigned)polys), dim3(512), 0, ctx->stream, ctx->K->d_bsk, (double *)ctx->h_out.p, polys, 1.0 / key_scale(ctx->fast_round));
     HIPCHK(ctx, hipGetLastError());
     CHK(to_host(ctx, bsk, ctx->h_out, polys * kN * sizeof(double)));
   }

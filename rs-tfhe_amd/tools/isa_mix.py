@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Instruction mix of the CMUX loop of k_blind_rotate<L, FAST=true>, read off the compiler's gfx950 assembly.
+"""Instruction mix of the CMUX loop of k_blind_rotate<L, FAST>, read off the compiler's gfx950 assembly, for the
+instantiation the reference's parameter sets of that l run: FAST (one-add rounding) at l = 3 (bgbit 6), the general
+rounding at l = 2 (SECURITY_UINT1, bgbit 10) and l = 1 (bgbit 18 .. 23) -- tfhe_hip_ctx_create's fast_round rule.
 
     hipcc --offload-arch=gfx950 -O3 ... -S --cuda-device-only -o tfhe_hip.s tfhe_hip.hip
     python3 isa_mix.py tfhe_hip.s [--json kernel_isa.json]
@@ -44,7 +46,7 @@ def klass(op):
 
 
 def mix(lines, L):
-    name = f"_ZN4tfhe14k_blind_rotateILi{L}ELb1EEEvNS_15BlindRotateArgsE"
+    name = f"_ZN4tfhe14k_blind_rotateILi{L}ELb{1 if L == 3 else 0}EEEvNS_15BlindRotateArgsE"
     start = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     blocks, cur = [], None

@@ -1070,6 +1070,35 @@ def test_cloud_key_export_is_identity(O, eng128, keys128):
     assert np.array_equal(out.blind_rotate_testvec, ck.blind_rotate_testvec)
 
 
+def test_cloud_key_export_is_identity_general_rounding_sets(O, keys_uint4):
+    """The same for a set that takes the general rounding (bgbit 22): its engine key carries a further 2^-32
+    (fft512.hpp key_scale / round_product) -- a power of two, so load -> export is still the identity -- and a key
+    generated on the GPU, exported and loaded into a second context gives the same ciphertext words."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys_uint4
+    pk = _cloud_key(ck)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    out = eng.export_cloud_key()
+    assert np.array_equal(out.bootstrapping_key, ck.bootstrapping_key)
+    assert np.array_equal(out.key_switching_key, ck.key_switching_key)
+    gen = eng.new_key_view()
+    gen.gen_cloud_key(sk.key_lv0, sk.key_lv1, 4321)
+    gk = gen.export_cloud_key()
+    other = eng.new_key_view()
+    other.load_cloud_key(gk)
+    assert np.array_equal(other.export_cloud_key().bootstrapping_key, gk.bootstrapping_key)
+    msgs = np.arange(200) % 16
+    cts = sk.encrypt_lwe_message(msgs, 16, 77)
+    lut = R.lut.Generator(16).generate_lookup_table(lambda x: (3 * x + 1) % 16)
+    a, b = gen.batch_bootstrap(cts, testvec=lut.poly), other.batch_bootstrap(cts, testvec=lut.poly)
+    assert np.array_equal(a, b)
+    assert np.array_equal(sk.decrypt_lwe_message(a, 16), (3 * msgs + 1) % 16)
+    for e in (gen, other, eng):
+        e.close()
+
+
 def test_gpu_key_generation(O, keys128):
     """CloudKey::new on the GPU (key.rs:59-66).  RNG streams differ from the host generator, so the
     bar is structural + functional: every sampled BSK row is a TRLWE encryption of the right gadget
