@@ -251,7 +251,15 @@ def pool_resident_mode(args, R, pool, sk, devices, B, keygen_s):
         "scatter_ms": round(tt["scatter_ms_max"], 3), "gather_ms": round(tt["gather_ms_max"], 3),
         "scatter_ms_sum_per_call": round(tt["scatter_ms_sum"] / calls, 3), "gather_ms_sum_per_call": round(tt["gather_ms_sum"] / calls, 3),
         "scatter_MB_per_call": round(tt["scatter_bytes"] / calls / 1e6, 1), "gather_MB_per_call": round(tt["gather_bytes"] / calls / 1e6, 1),
-        "pool_calls": tt["calls"], "keygen_and_replication_s": round(keygen_s, 3), "decrypt_ok": ok}), flush=True)
+        "pool_calls": tt["calls"],
+        # set-up, each on its own (host wall clock): key generation on member 0, the communicator's creation
+        # (ncclCommInitAll; 0 = the pool has none), the key's replication to the other members
+        "keygen_s": round(max(0.0, keygen_s - (tt["comm_create_ms"] + tt["key_replication_ms"]) * 1e-3), 3),
+        "comm_create_s": round(tt["comm_create_ms"] * 1e-3, 3), "key_replication_s": round(tt["key_replication_ms"] * 1e-3, 3),
+        # members that share a device exchange their shards by on-device copies: the times above then say nothing about
+        # xGMI (a pool of distinct devices is what they are for)
+        "transfers_cross_devices": len(set(devices)) == len(devices) and len(devices) > 1,
+        "decrypt_ok": ok}), flush=True)
 
 
 def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
@@ -292,6 +300,55 @@ def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
     return out
 
 
+def single_gate_latency(eng, gate, ca, cb, schedule=((0.0, 60), (0.010, 50), (1.0, 8), (10.0, 2))):
+    """BASELINE configs[0] through the GPU path: ONE `Gates::nand`-shaped call (host buffers in and out: two pageable
+    H2D copies, the latency kernels, one D2H copy, one stream synchronise), which is what the reference's criterion
+    `gate_nand` times on the CPU (benches/gate_benchmarks.rs:12-20).  A caller's gates do not arrive back to back, and
+    an idle GPU drops its clocks, so the call is timed after idle gaps: `schedule` = (gap seconds, calls); each call
+    sleeps `gap`, then runs and is timed on its own.  Returns, per gap, the median / min / max wall time of a call and
+    the median time of its kernels (HIP events on the launch stream): wall - kernels = copies + launches + wake-up,
+    and a kernel time that grows with the gap is the clock ramp."""
+    import statistics
+
+    eng.batch_gate(gate, ca[:1], cb[:1])
+    out = {}
+    k = 0
+    for gap, reps in schedule:
+        wall, kern = [], []
+        for _ in range(reps):
+            i = k % len(ca)
+            k += 1
+            if gap:
+                time.sleep(gap)
+            t1 = time.perf_counter()
+            eng.batch_gate(gate, ca[i:i + 1], cb[i:i + 1])
+            wall.append((time.perf_counter() - t1) * 1e3)
+        eng.kernel_times()
+        eng.set_profiling(True)
+        for _ in range(min(reps, 8)):
+            i = k % len(ca)
+            k += 1
+            if gap:
+                time.sleep(gap)
+            eng.batch_gate(gate, ca[i:i + 1], cb[i:i + 1])
+            kt = eng.kernel_times()
+            kern.append(kt["blind_rotate_ms"] + kt["key_switch_ms"])
+        eng.set_profiling(False)
+        out[f"{gap:g}s"] = {"calls": reps, "wall_ms_median": round(statistics.median(wall), 3), "wall_ms_min": round(min(wall), 3),
+                            "wall_ms_max": round(max(wall), 3), "kernels_ms_median": round(statistics.median(kern), 3)}
+    return out
+
+
+def free_port() -> int:
+    """A TCP port on 127.0.0.1 that is free now (bind to 0, read it back, release)."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        sock.bind(("127.0.0.1", 0))
+        return int(sock.getsockname()[1])
+
+
 def main():
     args = parse()
     if args.pool_devices:
@@ -301,8 +358,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not launched by torchrun: start it as a child (never exec after touching the GPU)
+        # the rendezvous port: MASTER_PORT if the caller set one, otherwise a port the kernel says is free right now
+        # (the driver's 1 -> 8 sweep starts this four times in a row on one node: a fixed port can meet a lingering
+        # listener of the previous run)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT") or str(free_port()),
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
@@ -346,10 +406,18 @@ def main():
     # driver's contract is one process per GPU; the timed calls go to the member context's *_dev entry points
     pool = R.Pool(P, [local_rank])
     eng = R.Engine.from_pool(pool, 0)
+    tk = time.perf_counter()
     if world == 1 or rank == 0:
         pool.gen_cloud_key(sk.key_lv0, sk.key_lv1, seed=2025)
+        eng.synchronize()
+    keygen_s = time.perf_counter() - tk
+    key_broadcast_s = None
     if world > 1:  # ONE key, generated on rank 0 and replicated device to device (RCCL broadcast, engine layouts)
+        dist.barrier()  # (the ranks that did not generate the key would otherwise count rank 0's key generation)
+        tk = time.perf_counter()
         R.distributed.broadcast_engine_key(eng, src=0)
+        torch.cuda.synchronize()
+        key_broadcast_s = time.perf_counter() - tk
     rng = np.random.default_rng(1000 + rank)
     bits_a = rng.integers(0, 2, B).astype(bool)
     bits_b = rng.integers(0, 2, B).astype(bool)
@@ -440,7 +508,23 @@ def main():
     except (OSError, ValueError):
         pass
 
+    # per-rank record (so that a bad scaling curve can be read from the line alone): this rank's own wall time for
+    # the K steps, its kernels' average launch times, its shader clock and its key-broadcast time
+    per_rank = None
     if world > 1:
+        mine = torch.tensor([elapsed, kt["blind_rotate_ms"] / max(1, kt["blind_rotate_launches"]),
+                             kt["key_switch_ms"] / max(1, kt["key_switch_launches"]), clk["shader_mhz"] or 0.0,
+                             key_broadcast_s or 0.0], dtype=torch.float64, device="cpu" if share else dev)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = [e.cpu().tolist() for e in every]
+        per_rank = {
+            "ms_per_step": [round(e[0] / args.steps * 1e3, 2) for e in every],
+            "blind_rotate_ms": [round(e[1], 2) for e in every],
+            "key_switch_ms": [round(e[2], 3) for e in every],
+            "shader_mhz": [round(e[3]) for e in every],
+            "key_broadcast_s": [round(e[4], 3) for e in every],
+        }
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -459,6 +543,10 @@ def main():
     else:
         decrypt_ok = bool(np.array_equal(sk.decrypt_bool(out), GATE_TRUTH[args.gate](bits_a, bits_b)))
 
+    if world > 1 and decrypt_ok is not None:  # every rank checked its own shard: the line's flag is the AND over ranks
+        flag = torch.tensor([1 if decrypt_ok else 0], dtype=torch.int32, device="cpu" if share else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        decrypt_ok = bool(flag.item())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -518,9 +606,10 @@ def main():
         print("bench.py: " + isa_source, file=sys.stderr)
     wave_steps_per_s = P.n * per_launch / (br_ms * 1e-3) if br_ms > 0 else 0.0  # CMUX steps of one wave, whole chip
     tflops = wave_steps_per_s * 64 * isa["f64_flop_per_lane"] / 1e12
-    # SURVEY 8(d)'s ALGORITHMIC flops per CMUX step (the contract figure): (2l+2) transforms of 26,112 flops + 2l digit
-    # rows x 2 spectra x 512 complex MACs of 8 flops = 258,048 at l = 3, 120,832 at l = 1.  `frac` prices the flops the
-    # kernel EXECUTES (from its ISA: a few per cent more -- twiddle folding, the rounding); both are printed.
+    # SURVEY 8(d)'s ALGORITHMIC flops per CMUX step (the contract figure, `roofline.frac`): (2l+2) transforms of 26,112
+    # flops + 2l digit rows x 2 spectra x 512 complex MACs of 8 flops = 258,048 at l = 3, 120,832 at l = 1.
+    # `frac_executed` prices the flops the kernel EXECUTES (from its ISA: a few per cent more -- twiddle folding, the
+    # rounding); both are printed.
     alg_flop_per_step = (2 * P.l + 2) * 26112 + 2 * P.l * 8192
     tflops_alg = wave_steps_per_s * alg_flop_per_step / 1e12
     plan = eng.describe_dispatch(int(per_launch)) if per_launch else ""
@@ -532,13 +621,15 @@ def main():
     roofline = {
         "kernel": f"k_blind_rotate<{P.l}>",
         "bound": "fp64_valu",
-        "achieved": round(tflops, 2),
+        # the contract figure: SURVEY 8(d)'s ALGORITHMIC flops per launch over the HIP-event launch duration
+        "achieved": round(tflops_alg, 2),
         "peak": 78.6,
         "unit": "TFLOP/s",
-        "frac": round(tflops / 78.6, 4),
-        "achieved_algorithmic": round(tflops_alg, 2),
-        "frac_algorithmic": round(tflops_alg / 78.6, 4),
+        "frac": round(tflops_alg / 78.6, 4),
         "algorithmic_flop_per_cmux_step": alg_flop_per_step,
+        # the flops the kernel EXECUTES (from the ISA of this build: a few per cent more -- twiddle folding, rounding)
+        "achieved_executed": round(tflops, 2),
+        "frac_executed": round(tflops / 78.6, 4),
         "dispatch": plan,
         "traffic": traffic,
         "traffic_source": traffic_source,
@@ -553,15 +644,17 @@ def main():
         "board_power_w": power_w,
         "board_power_cap_w": power_cap_w,
         # the same flops against the FP64 peak AT THE SUSTAINED CLOCK (the board is power-capped: DESIGN.md section 5)
-        "frac_at_sustained_clock": round(tflops / (78.6 * shader_mhz / 2400.0), 4) if shader_mhz else None,
+        "frac_at_sustained_clock": round(tflops_alg / (78.6 * shader_mhz / 2400.0), 4) if shader_mhz else None,
+        "frac_executed_at_sustained_clock": round(tflops / (78.6 * shader_mhz / 2400.0), 4) if shader_mhz else None,
         # what this board sustains on nothing but v_fma_f64 over random operands (profiles/exp/logs/r2u_ubench_random_operands.log):
         # the 1,400 W cap holds that stream at 2,027 MHz = 66.4 TFLOP/s
-        "frac_of_power_capped_fma_peak": round(tflops / 66.4, 4),
+        "frac_executed_of_power_capped_fma_peak": round(tflops / 66.4, 4),
         "valu_issue_frac": round(wave_steps_per_s * isa["valu"] * 4 / simd_cycles_per_s, 4) if have_isa else None,
         "f64_issue_frac": round(wave_steps_per_s * f64_instr * 4 / simd_cycles_per_s, 4) if have_isa else None,
         # every bootstrap "consumes" the whole key once.  The key is shared through L1/L2, so this
         # exceeds the HBM peak by construction and is NOT a roofline fraction; physical_hbm_frac is.
         "algorithmic_hbm": {
+            "note": "figure of merit, NOT a bound: the key is shared by every ciphertext in flight (L1/L2 hits), so the ratio exceeds 1; physical_hbm_frac is the fraction of HBM bandwidth used",
             "achieved_GBps": round(achieved, 1), "peak_GBps": 8000.0, "ratio": round(achieved / 8000.0, 4),
             "bytes_per_launch": int(br_bytes_per_ct * per_launch),
             "whole_path_GBps": round(value / world * bytes_per_bootstrap / 1e9, 1),
@@ -628,16 +721,16 @@ def main():
             O.batch_gate(ock, gate, ca[r_:r_ + 1], cb[r_:r_ + 1], nthreads=1)
         single_ms = (time.perf_counter() - t1) / 3 * 1e3
         O.batch_gate(ock, gate, ca[:1], cb[:1], nthreads=allt)  # restore the OpenMP team size
-        # the same single gate through the GPU path (host buffers, includes PCIe + sync)
-        eng.batch_gate(gate, ca[:1], cb[:1])
-        t1 = time.perf_counter()
-        for r_ in range(5):
-            eng.batch_gate(gate, ca[r_:r_ + 1], cb[r_:r_ + 1])
-        gpu_single_ms = (time.perf_counter() - t1) / 5 * 1e3
+        # the same single gate through the GPU path (host buffers, includes PCIe + sync), back to back and after idle
+        # gaps (single_gate_latency): `gpu_single_gate_ms_warm` = median of back-to-back calls, `..._after_idle` =
+        # median of calls that each follow 1 s of idle; the whole table is in `gpu_single_gate_latency`
+        lat = single_gate_latency(eng, gate, ca, cb)
         cpu = {
             "value": round(best[0], 2),
             "single_gate_ms_1core": round(single_ms, 2),
-            "gpu_single_gate_ms": round(gpu_single_ms, 2),
+            "gpu_single_gate_ms_warm": lat["0s"]["wall_ms_median"],
+            "gpu_single_gate_ms_after_idle": lat["1s"]["wall_ms_median"],
+            "gpu_single_gate_latency": lat,
             "unit": "bootstraps/s",
             "cores": threads,
             "kind": "port",
@@ -674,6 +767,14 @@ def main():
         "cpu_baseline": cpu,
         "decrypt_ok": decrypt_ok,
         "setup_s": round(setup_s, 1),
+        "keygen_s": round(keygen_s, 3),
+        # N > 1: how the one key reached the other ranks' GPUs and how long that took (max over ranks); the data path
+        # itself has no collective
+        "key_broadcast_s": round(max(per_rank["key_broadcast_s"]), 3) if per_rank else None,
+        "key_broadcast_backend": (dist.get_backend() if world > 1 else None),
+        "per_rank": per_rank,
+        "ms_per_step_min_rank": min(per_rank["ms_per_step"]) if per_rank else None,
+        "ms_per_step_max_rank": max(per_rank["ms_per_step"]) if per_rank else None,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

@@ -384,6 +384,13 @@ int tfhe_hip_get_key_switch_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sampl
  * experiment builds (-DTFHE_EXPERIMENT, profiles/exp/build_variants.sh) and are not part of this interface. */
 int tfhe_hip_describe_dispatch(tfhe_hip_ctx *ctx, size_t count, char *buf, size_t buflen);
 
+/* How this context's blind-rotation kernels round the external product (KlemsaProcessor::fft's `round() as i64 as u32`,
+ * src/fft/klemsa.rs:145-146): "fast" when the parameter set bounds the pre-rounding magnitude below 2^51
+ * (2l * N * Bg/2 * 2^31: the 128 / 110 / 80-bit sets) and one add does it, "general" otherwise (|x| < 2^63: the
+ * multiple of 2^32 is peeled off first; the l = 1 and l = 2 message-space sets).  Both give the reference's bits
+ * wherever the f64 product is exact.  Chosen at tfhe_hip_ctx_create from (l, bgbit); constant for the context. */
+const char *tfhe_hip_rounding_mode(const tfhe_hip_ctx *ctx);
+
 /* Block until everything this context enqueued -- on its own stream and on the caller's stream of the
  * last *_dev call -- has finished.  Returns TFHE_HIP_EINVAL (and clears the condition) if a
  * tfhe_hip_batch_gates_mixed_dev launch since the last call met a gate code outside tfhe_hip_gate. */
@@ -506,13 +513,18 @@ const char *tfhe_hip_pool_data_transport(const tfhe_hip_pool *pool);
 /* Measurement: tfhe_hip_set_profiling on every member, plus HIP-event pairs around every shard transfer of the *_dev
  * pool calls.  tfhe_hip_pool_get_transfer_times synchronises those events, returns the sums since the last call and
  * resets them: *_ms_sum over all transfers, *_ms_max the longest single one (transfers to different peers overlap).
- * A scatter is timed on the receiving member's stream; a gather on the sending member's stream (peer copies) or on
- * the home stream (RCCL: one grouped receive, which also waits for the slowest member's result). */
+ * Each moved shard is bracketed on the member's stream (the receiver of a scatter, the sender of a gather; a
+ * gather's bracket opens after the member's compute); on the RCCL path the call's group is bracketed on the home
+ * stream too, and a shard's time is the SHORTER of the two: a transfer starts when both ends have reached it, so the
+ * end that arrived last brackets the transfer alone and the other one also brackets its wait for the peer.
+ * comm_create_ms / key_replication_ms are host wall-clock set-up costs and are NOT reset by reading: the creation of
+ * the pool's persistent communicator (0 when it has none) and the last replication of a cloud key to the members. */
 typedef struct tfhe_hip_pool_transfer_times {
   double scatter_ms_sum, scatter_ms_max;
   double gather_ms_sum, gather_ms_max;
   uint64_t scatter_bytes, gather_bytes;
   uint64_t calls; /* *_dev pool calls since the last read */
+  double comm_create_ms, key_replication_ms;
 } tfhe_hip_pool_transfer_times;
 int tfhe_hip_pool_set_profiling(tfhe_hip_pool *pool, int enabled);
 int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *pool, tfhe_hip_pool_transfer_times *out);

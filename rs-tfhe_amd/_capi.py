@@ -50,7 +50,7 @@ class PoolTransferTimes(C.Structure):
 
     _fields_ = [("scatter_ms_sum", C.c_double), ("scatter_ms_max", C.c_double), ("gather_ms_sum", C.c_double),
                 ("gather_ms_max", C.c_double), ("scatter_bytes", C.c_uint64), ("gather_bytes", C.c_uint64),
-                ("calls", C.c_uint64)]
+                ("calls", C.c_uint64), ("comm_create_ms", C.c_double), ("key_replication_ms", C.c_double)]
 
 
 _P = C.c_void_p
@@ -112,6 +112,7 @@ SIGNATURES = {
     "tfhe_hip_get_key_switch_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
     "tfhe_hip_describe_dispatch": (C.c_int, [_CTX, _SZ, C.c_char_p, _SZ]),
+    "tfhe_hip_rounding_mode": (C.c_char_p, [_CTX]),
     # several GPUs behind one handle
     "tfhe_hip_pool_create": (C.c_int, [C.POINTER(Params), C.POINTER(C.c_int), C.c_int, C.POINTER(_CTX)]),
     "tfhe_hip_pool_destroy": (None, [_CTX]),

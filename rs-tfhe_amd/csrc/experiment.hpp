@@ -1,6 +1,6 @@
 // experiment.hpp -- guard for the timing-only ablation switches used by profiles/exp/ (NOT product behaviour).
 //
-// TFHE_ABL_NOKEY / NOLDS / NOFFT / TPB_DPP / KM_NOBARRIER remove or replace parts of the kernels so that the cost of what
+// TFHE_ABL_NOKEY / NOLDS / NOFFT / TPB_DPP / KM_NOBARRIER / ROUND_LSB remove, replace or falsify parts of the kernels so that the cost of what
 // is left can be measured (profiles/exp/logs/r2h_ab_energy_decomposition.log); the results of such a build are
 // WRONG BY CONSTRUCTION.  They can only be switched on together with -DTFHE_EXPERIMENT (what
 // profiles/exp/build_variants.sh passes); such a library reports itself as "hip-gfx950-EXPERIMENT" through
@@ -9,7 +9,7 @@
 #if (defined(TFHE_ABL_NOKEY) && TFHE_ABL_NOKEY) || (defined(TFHE_ABL_NOLDS) && TFHE_ABL_NOLDS) || \
     (defined(TFHE_ABL_NOFFT) && TFHE_ABL_NOFFT) || (defined(TFHE_ABL_TPB_DPP) && TFHE_ABL_TPB_DPP) || \
     (defined(TFHE_ABL_KM_NOBARRIER) && TFHE_ABL_KM_NOBARRIER) || (defined(TFHE_ABL_LAT) && TFHE_ABL_LAT) || \
-    (defined(TFHE_ABL_SL) && TFHE_ABL_SL)
+    (defined(TFHE_ABL_SL) && TFHE_ABL_SL) || (defined(TFHE_ABL_ROUND_LSB) && TFHE_ABL_ROUND_LSB)
 #ifndef TFHE_EXPERIMENT
 #error "TFHE_ABL_* are timing-only experiment switches (results wrong by construction): build with -DTFHE_EXPERIMENT (profiles/exp/build_variants.sh)"
 #endif
@@ -32,6 +32,10 @@
 #ifndef TFHE_ABL_LAT  // latency kernels. wide: bit 0 no exchange of partial products, bit 1 no rotated reads / digits, bit 2 no update;
                       // wide2: 8 no forward FFT, 16 no inverse FFT, 32 no MAC phase, 64 no key loads in the loop, 128 no digit preparation
 #define TFHE_ABL_LAT 0
+#endif
+#ifndef TFHE_ABL_ROUND_LSB  // mutation, not timing: round_product<false> returns one LSB too much on ~1/1024 of the words, so that
+                            // the parity suite can be shown to notice (the l = 1 exact-regime tests must FAIL on this build)
+#define TFHE_ABL_ROUND_LSB 0
 #endif
 #ifndef TFHE_ABL_KM_NOBARRIER  // matrix-core key switch without its per-step barrier (races: wrong results)
 #define TFHE_ABL_KM_NOBARRIER 0

@@ -11,6 +11,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: the library is opened at run time (rccl_api)
 
+#include <chrono>
 #include <system_error>
 #include <thread>
 
@@ -21,7 +22,7 @@ struct tfhe_hip_pool {
   int views = 0;                    // live key views (root only)
   bool dying = false;               // destroyed while views were alive: the last view to go frees the pool
   FairMutex own_mu;  // one call at a time per ROOT pool, first come first served: a view's calls serialise with its parent's (they share streams and staging)
-  uint64_t id = g_next_handle_id.fetch_add(1);  // key of the per-thread error text (err_slot)
+  uint64_t id = new_handle_id();  // key of the per-thread error text (err_slot)
   bool replicated_by_rccl = false;  // how the last key reached the members (tfhe_hip_pool_key_transport)
   // ---- root only: what the device-resident (_dev) calls and the key replication share ----
   std::vector<ncclComm_t> comms;    // ONE persistent communicator per pool (created on first use, destroyed with the pool)
@@ -34,11 +35,24 @@ struct tfhe_hip_pool {
   hipEvent_t ready = nullptr;       // recorded on the home stream when the call's operands are ready (peer-copy path)
   int ready_device = -1;
   const char *last_transport = "none";  // transport of the last _dev call: "rccl" / "peer-copy" / "none" (nothing moved)
-  // transfer timing (tfhe_hip_pool_get_transfer_times): event pairs on the receiving stream, per moved shard
+  // transfer timing (tfhe_hip_pool_get_transfer_times): per moved shard one event pair on the MEMBER's stream (the
+  // receiver of a scatter, the sender of a gather); on the RCCL path also one pair per call and direction on the HOME
+  // stream around the group (`home_ix` into ev_home).  A transfer can only start when BOTH ends have reached it, so
+  // the pair of the side that arrived last brackets the transfer alone and the other one also brackets its wait for
+  // the peer (e.g. the home stream's receive group waits for the slowest member's compute): a shard's transfer time
+  // is the SHORTER of its two brackets.
+  struct Timed {
+    hipEvent_t a = nullptr, b = nullptr;
+    int member = 0;    // whose device the events live on
+    long home_ix = -1;  // RCCL: the call's home-stream pair
+  };
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_scatter, ev_gather;
-  std::vector<int> ev_scatter_dev, ev_gather_dev;
+  std::vector<Timed> ev_scatter, ev_gather, ev_home;
   uint64_t scatter_bytes = 0, gather_bytes = 0, dev_calls = 0;
+  // set-up costs, host wall clock (not reset by reading): creating the persistent communicator (ncclCommInitAll, once
+  // per pool) and the last replication of a cloud key to the members (ncclBroadcast or peer copies + the members'
+  // byte-plane builds), so that neither hides inside a "key generation" figure
+  double comm_create_ms = 0.0, key_replication_ms = 0.0;
 
   tfhe_hip_pool *root() { return parent ? parent : this; }
   const tfhe_hip_pool *root() const { return parent ? parent : this; }
@@ -97,6 +111,7 @@ struct RcclApi {
   void *lib = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -114,6 +129,7 @@ inline RcclApi &rccl_api() {
     if (!r.lib) return r;
     r.CommInitAll = (decltype(r.CommInitAll))dlsym(r.lib, "ncclCommInitAll");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+    r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
     r.GroupStart = (decltype(r.GroupStart))dlsym(r.lib, "ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))dlsym(r.lib, "ncclGroupEnd");
     r.Broadcast = (decltype(r.Broadcast))dlsym(r.lib, "ncclBroadcast");
@@ -150,7 +166,9 @@ std::vector<ncclComm_t> *pool_comms(tfhe_hip_pool *p) {
   int prev = -1;
   (void)hipGetDevice(&prev);
   std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  const auto t0 = std::chrono::steady_clock::now();
   const bool good = R.CommInitAll(comms.data(), n, devs.data()) == ncclSuccess;
+  root->comm_create_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (prev >= 0) (void)hipSetDevice(prev);
   if (!good) {
     (void)hipGetLastError();
@@ -159,6 +177,21 @@ std::vector<ncclComm_t> *pool_comms(tfhe_hip_pool *p) {
   root->comms = std::move(comms);
   root->comm_state = 1;
   return &root->comms;
+}
+
+// A call failed INSIDE an open RCCL group (or its GroupEnd did): sends / receives of the group may have been launched
+// without their partners, so the communicator's state is undefined and the streams it was used on may never drain.
+// The pool stops using it: the communicators are aborted (ncclCommAbort where the library has it, which also releases
+// kernels that wait for a partner) and every later call takes the peer-copy path.
+void pool_drop_comms(tfhe_hip_pool *p) {
+  tfhe_hip_pool *root = p->root();
+  if (root->comm_state != 1) return;
+  RcclApi &R = rccl_api();
+  for (ncclComm_t c : root->comms)
+    if (c) (void)(R.CommAbort ? R.CommAbort(c) : R.CommDestroy(c));
+  root->comms.clear();
+  root->comm_state = -1;
+  (void)hipGetLastError();
 }
 
 // member i >= 1: drained, its key buffers allocated, no valid key until finish_replica
@@ -228,6 +261,7 @@ bool replicate_key_rccl(tfhe_hip_pool *p) {
   held.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
   if (!good) {
+    pool_drop_comms(p);  // a broadcast group that failed half-way: the communicator is not used again
     (void)hipGetLastError();
     return false;
   }
@@ -239,6 +273,19 @@ bool replicate_key_rccl(tfhe_hip_pool *p) {
 
 int replicate_key(tfhe_hip_pool *p) {
   p->replicated_by_rccl = false;
+  tfhe_hip_pool *root = p->root();
+  const bool had_comm = root->comm_state == 1;
+  auto t0 = std::chrono::steady_clock::now();
+  struct Stamp {  // (the communicator's creation, when this call caused it, is reported on its own)
+    tfhe_hip_pool *root;
+    std::chrono::steady_clock::time_point t0;
+    bool had_comm;
+    ~Stamp() {
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (!had_comm && root->comm_state == 1) ms -= root->comm_create_ms;
+      root->key_replication_ms = ms > 0 ? ms : 0.0;
+    }
+  } stamp{root, t0, had_comm};
   if (replicate_key_rccl(p)) return TFHE_HIP_OK;
   for (size_t i = 1; i < p->ctxs.size(); ++i) {
     const int rc = clone_key(p->ctxs[i], p->ctxs[0]);
@@ -361,24 +408,26 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   };
   // transfer timing: begin records the first event of a new pair on `s` and returns the pair's index (-1: off), end
   // records the second event of pair `idx`
-  auto timed_begin = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, int member, hipStream_t s) -> long {
+  using TimedVec = std::vector<tfhe_hip_pool::Timed>;
+  auto timed_begin = [&](TimedVec &v, int member, hipStream_t s, long home_ix = -1) -> long {
     if (!root->timing || v.size() >= 4096) return -1;  // (a caller that never collects: stop at 4,096 pending pairs)
     (void)hipSetDevice(p->ctxs[(size_t)member]->device);
-    hipEvent_t a = nullptr, b = nullptr;
-    if (hipEventCreate(&a) != hipSuccess) return -1;
-    if (hipEventCreate(&b) != hipSuccess) {
-      (void)hipEventDestroy(a);
+    tfhe_hip_pool::Timed t;
+    if (hipEventCreate(&t.a) != hipSuccess) return -1;
+    if (hipEventCreate(&t.b) != hipSuccess) {
+      (void)hipEventDestroy(t.a);
       return -1;
     }
-    (void)hipEventRecord(a, s);
-    v.emplace_back(a, b);
-    devs.push_back(member);
+    (void)hipEventRecord(t.a, s);
+    t.member = member;
+    t.home_ix = home_ix;
+    v.push_back(t);
     return (long)v.size() - 1;
   };
-  auto timed_end = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, long idx, int member, hipStream_t s) {
+  auto timed_end = [&](TimedVec &v, long idx, hipStream_t s) {
     if (idx < 0) return;
-    (void)hipSetDevice(p->ctxs[(size_t)member]->device);
-    (void)hipEventRecord(v[(size_t)idx].second, s);
+    (void)hipSetDevice(p->ctxs[(size_t)v[(size_t)idx].member]->device);
+    (void)hipEventRecord(v[(size_t)idx].b, s);
   };
   // shard table: shard r -> member, [lo, hi), remote?
   struct Sh {
@@ -415,9 +464,26 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   if (any_remote) {
     root->last_transport = comms ? "rccl" : "peer-copy";
     if (comms) {
+      // everything that can fail for a reason of ours is checked BEFORE the group opens (every device can be made
+      // current, every staging buffer exists): inside it only the RCCL calls themselves can fail, and if one does the
+      // communicator is dropped (pool_drop_comms) -- a send that was launched without its receive may never complete,
+      // so after such an error the home stream may be poisoned and the caller should not wait on it
+      for (const Sh &sh : shards) {
+        if (!sh.remote) continue;
+        const hipError_t e = hipSetDevice(p->ctxs[(size_t)sh.member]->device);
+        if (e != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
+        for (int k = 0; k < 5; ++k)
+          if (ins[k].ptr && !root->stage[(size_t)sh.member].in[k].p) return pool_fail(p, TFHE_HIP_EHIP, "pool staging buffer missing");
+      }
+      {
+        const hipError_t e = hipSetDevice(hctx->device);
+        if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
+      }
+      // (events go in before the group opens: inside it nothing is enqueued yet)
+      const long hix = timed_begin(root->ev_home, home, hrt);
       std::vector<long> tix(shards.size(), -1);
-      for (size_t q = 0; q < shards.size(); ++q)  // (events go in before the group opens: inside it nothing is enqueued yet)
-        if (shards[q].remote) tix[q] = timed_begin(root->ev_scatter, root->ev_scatter_dev, shards[q].member, member_stream(shards[q].member));
+      for (size_t q = 0; q < shards.size(); ++q)
+        if (shards[q].remote) tix[q] = timed_begin(root->ev_scatter, shards[q].member, member_stream(shards[q].member), hix);
       if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (scatter)");
       bool good = true;  // (a group that was opened is always closed, whatever fails inside it)
       for (const Sh &sh : shards) {
@@ -436,8 +502,12 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
       }
       good = (R.GroupEnd() == ncclSuccess) && good;
       for (size_t q = 0; q < shards.size(); ++q)
-        if (shards[q].remote) timed_end(root->ev_scatter, tix[q], shards[q].member, member_stream(shards[q].member));
-      if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL scatter (ncclSend / ncclRecv) failed");
+        if (shards[q].remote) timed_end(root->ev_scatter, tix[q], member_stream(shards[q].member));
+      timed_end(root->ev_home, hix, hrt);
+      if (!good) {
+        pool_drop_comms(p);
+        return pool_fail(p, TFHE_HIP_EHIP, "RCCL scatter (ncclSend / ncclRecv) failed inside the group: communicator dropped, later calls use peer copies; the home stream may not drain");
+      }
     } else {
       hipError_t e = hipSetDevice(hctx->device);
       if (e != hipSuccess) return hipfail("hipSetDevice", e, home);
@@ -455,7 +525,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         hipStream_t ms = member_stream(sh.member);
         if ((e = hipSetDevice(ddev)) != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
         if ((e = hipStreamWaitEvent(ms, root->ready, 0)) != hipSuccess) return hipfail("hipStreamWaitEvent", e, sh.member);
-        const long tix = timed_begin(root->ev_scatter, root->ev_scatter_dev, sh.member, ms);
+        const long tix = timed_begin(root->ev_scatter, sh.member, ms);
         for (int k = 0; k < 5; ++k) {
           if (!ins[k].ptr) continue;
           const size_t bytes = ins[k].sharded ? (sh.hi - sh.lo) * ins[k].row_bytes : ins[k].row_bytes;
@@ -464,7 +534,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
             return hipfail("hipMemcpyPeerAsync (scatter)", e, sh.member);
           root->scatter_bytes += bytes;
         }
-        timed_end(root->ev_scatter, tix, sh.member, ms);
+        timed_end(root->ev_scatter, tix, ms);
       }
     }
   }
@@ -491,7 +561,13 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
   // 4. gather
   if (any_remote) {
     if (comms) {
-      const long gix = timed_begin(root->ev_gather, root->ev_gather_dev, home, hrt);
+      // per shard a pair on the SENDING member's stream (its first event follows the member's compute, so the pair
+      // brackets the transfer and whatever it waits for on the home side); one pair on the home stream around the
+      // group's receives (which also waits for the slowest member's result)
+      const long hix = timed_begin(root->ev_home, home, hrt);
+      std::vector<long> gix(shards.size(), -1);
+      for (size_t q = 0; q < shards.size(); ++q)
+        if (shards[q].remote) gix[q] = timed_begin(root->ev_gather, shards[q].member, member_stream(shards[q].member), hix);
       if (R.GroupStart() != ncclSuccess) return pool_fail(p, TFHE_HIP_EHIP, "ncclGroupStart (gather)");
       bool good = true;
       for (const Sh &sh : shards) {
@@ -505,8 +581,13 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         root->gather_bytes += bytes;
       }
       good = (R.GroupEnd() == ncclSuccess) && good;
-      timed_end(root->ev_gather, gix, home, hrt);
-      if (!good) return pool_fail(p, TFHE_HIP_EHIP, "RCCL gather (ncclSend / ncclRecv) failed");
+      for (size_t q = 0; q < shards.size(); ++q)
+        if (shards[q].remote) timed_end(root->ev_gather, gix[q], member_stream(shards[q].member));
+      timed_end(root->ev_home, hix, hrt);
+      if (!good) {
+        pool_drop_comms(p);
+        return pool_fail(p, TFHE_HIP_EHIP, "RCCL gather (ncclSend / ncclRecv) failed inside the group: communicator dropped, later calls use peer copies; the home stream may not drain");
+      }
     } else {
       for (const Sh &sh : shards) {
         if (!sh.remote) continue;
@@ -516,10 +597,10 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
         const size_t bytes = (sh.hi - sh.lo) * out_row_bytes;
         hipError_t e = hipSetDevice(sdev);
         if (e != hipSuccess) return hipfail("hipSetDevice", e, sh.member);
-        const long gix = timed_begin(root->ev_gather, root->ev_gather_dev, sh.member, ms);
+        const long gix = timed_begin(root->ev_gather, sh.member, ms);
         if ((e = hipMemcpyPeerAsync((unsigned char *)out + sh.lo * out_row_bytes, hctx->device, st.out.p, sdev, bytes, ms)) != hipSuccess)
           return hipfail("hipMemcpyPeerAsync (gather)", e, sh.member);
-        timed_end(root->ev_gather, gix, sh.member, ms);
+        timed_end(root->ev_gather, gix, ms);
         if ((e = hipEventRecord(st.done, ms)) != hipSuccess) return hipfail("hipEventRecord", e, sh.member);
         root->gather_bytes += bytes;
       }
@@ -588,7 +669,7 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
       for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);  // (drains the member's queued work first)
       last_of_dying = --root->views == 0 && root->dying;
     }
-    t_errors.erase(p->id);
+    handle_gone(p->id);
     delete p;
     if (last_of_dying) tfhe_hip_pool_destroy(root);  // the parent was destroyed first: it has waited for its views
     return;
@@ -619,14 +700,14 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
     if (p->stage[i].done) (void)hipEventDestroy(p->stage[i].done);
   }
   if (p->ready) (void)hipEventDestroy(p->ready);
-  for (auto *v : {&p->ev_scatter, &p->ev_gather})
+  for (auto *v : {&p->ev_scatter, &p->ev_gather, &p->ev_home})
     for (auto &e : *v) {
-      (void)hipEventDestroy(e.first);
-      (void)hipEventDestroy(e.second);
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
     }
   if (prev >= 0) (void)hipSetDevice(prev);
   for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);
-  t_errors.erase(p->id);
+  handle_gone(p->id);
   delete p;
 }
 
@@ -661,7 +742,7 @@ tfhe_hip_ctx *tfhe_hip_pool_ctx(tfhe_hip_pool *p, int i) {
   return (p && i >= 0 && (size_t)i < p->ctxs.size()) ? p->ctxs[(size_t)i] : nullptr;
 }
 
-const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? err_slot(p->id).c_str() : g_create_error.c_str(); }
+const char *tfhe_hip_pool_last_error(const tfhe_hip_pool *p) { return p ? err_text(p->id) : g_create_error.c_str(); }
 
 // "rccl" when the pool's last cloud key reached its members by ncclBroadcast, "peer-copy" when by hipMemcpyPeer
 // (or when there was nothing to replicate).
@@ -933,28 +1014,44 @@ int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *p, tfhe_hip_pool_transfer_ti
   memset(out, 0, sizeof(*out));
   int prev = -1;
   (void)hipGetDevice(&prev);
-  auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>> &v, std::vector<int> &devs, double &sum, double &mx) {
-    for (size_t i = 0; i < v.size(); ++i) {
-      if (i < devs.size()) (void)hipSetDevice(root->ctxs[(size_t)devs[i]]->device);
-      float t = 0.f;
-      if (hipEventSynchronize(v[i].second) == hipSuccess && hipEventElapsedTime(&t, v[i].first, v[i].second) == hipSuccess) {
-        sum += (double)t;
-        if ((double)t > mx) mx = (double)t;
-      } else {
-        (void)hipGetLastError();
+  auto elapsed = [&](tfhe_hip_pool::Timed &t) -> double {  // < 0: not measurable
+    (void)hipSetDevice(root->ctxs[(size_t)t.member]->device);
+    float ms = 0.f;
+    if (hipEventSynchronize(t.b) == hipSuccess && hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) return (double)ms;
+    (void)hipGetLastError();
+    return -1.0;
+  };
+  std::vector<double> home_ms(root->ev_home.size(), -1.0);
+  for (size_t i = 0; i < root->ev_home.size(); ++i) home_ms[i] = elapsed(root->ev_home[i]);
+  auto drain = [&](std::vector<tfhe_hip_pool::Timed> &v, double &sum, double &mx) {
+    for (auto &t : v) {
+      double ms = elapsed(t);
+      // RCCL path: the shorter of the member-side and the home-side bracket (see tfhe_hip_pool::Timed)
+      if (t.home_ix >= 0 && (size_t)t.home_ix < home_ms.size() && home_ms[(size_t)t.home_ix] >= 0 &&
+          (ms < 0 || home_ms[(size_t)t.home_ix] < ms))
+        ms = home_ms[(size_t)t.home_ix];
+      if (ms >= 0) {
+        sum += ms;
+        if (ms > mx) mx = ms;
       }
-      (void)hipEventDestroy(v[i].first);
-      (void)hipEventDestroy(v[i].second);
+      (void)hipEventDestroy(t.a);
+      (void)hipEventDestroy(t.b);
     }
     v.clear();
-    devs.clear();
   };
-  drain(root->ev_scatter, root->ev_scatter_dev, out->scatter_ms_sum, out->scatter_ms_max);
-  drain(root->ev_gather, root->ev_gather_dev, out->gather_ms_sum, out->gather_ms_max);
+  drain(root->ev_scatter, out->scatter_ms_sum, out->scatter_ms_max);
+  drain(root->ev_gather, out->gather_ms_sum, out->gather_ms_max);
+  for (auto &t : root->ev_home) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  root->ev_home.clear();
   if (prev >= 0) (void)hipSetDevice(prev);
   out->scatter_bytes = root->scatter_bytes;
   out->gather_bytes = root->gather_bytes;
   out->calls = root->dev_calls;
+  out->comm_create_ms = root->comm_create_ms;
+  out->key_replication_ms = root->key_replication_ms;
   root->scatter_bytes = root->gather_bytes = root->dev_calls = 0;
   return TFHE_HIP_OK;
 }

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -47,9 +48,42 @@ thread_local std::string g_create_error = "";
 // message -- not a string another thread is assigning or has freed.  Every context and pool carries an id that is
 // never reused; the text lives in a thread-local table keyed by it, and tfhe_hip_last_error() returns the calling
 // thread's entry (valid until that thread's next failing call on the same handle).
+// A handle's entry is erased by the thread that destroys it; entries other threads made for it would stay for those
+// threads' lifetimes (a long-lived worker that fails once on each of many short-lived contexts), so the table is bounded:
+// when a thread's table has grown past kErrTableSoftCap entries, the next failure on that thread drops the entries of
+// handles that no longer exist (g_live_handles).  Reading never inserts.
 std::atomic<uint64_t> g_next_handle_id{1};
 thread_local std::unordered_map<uint64_t, std::string> t_errors;
-inline std::string &err_slot(uint64_t id) { return t_errors[id]; }  // (references survive rehashing)
+std::mutex g_live_mu;
+std::unordered_set<uint64_t> g_live_handles;
+constexpr size_t kErrTableSoftCap = 64;
+inline uint64_t new_handle_id() {  // never reused
+  const uint64_t id = g_next_handle_id.fetch_add(1);
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  g_live_handles.insert(id);
+  return id;
+}
+inline void handle_gone(uint64_t id) {
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_handles.erase(id);
+  }
+  t_errors.erase(id);
+}
+// the slot a FAILING call writes its text into (references survive rehashing)
+inline std::string &err_slot(uint64_t id) {
+  if (t_errors.size() >= kErrTableSoftCap && !t_errors.count(id)) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    for (auto it = t_errors.begin(); it != t_errors.end();) it = g_live_handles.count(it->first) ? std::next(it) : t_errors.erase(it);
+  }
+  return t_errors[id];
+}
+// the calling thread's last failure text on handle `id`, "" if it never failed there (no entry is made)
+inline const char *err_text(uint64_t id) {
+  static const std::string none;
+  const auto it = t_errors.find(id);
+  return it == t_errors.end() ? none.c_str() : it->second.c_str();
+}
 
 constexpr int kKsG = 32;  // ciphertexts per key-switch workgroup
 
@@ -116,7 +150,7 @@ struct tfhe_hip_ctx {
   PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
   bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
   FairMutex mu;  // one call at a time per context, first come first served
-  uint64_t id = g_next_handle_id.fetch_add(1);  // key of this context's per-thread error text (err_slot)
+  uint64_t id = new_handle_id();  // key of this context's per-thread error text (err_slot)
   bool profiling = false;
   int num_cus = 0;
   bool fast_round = false;  // |pre-rounding value| < 2^51 guaranteed (see round_to_torus<FAST>)
@@ -958,7 +992,7 @@ const char *tfhe_hip_name(void) { return TFHE_ABLATED ? "hip-gfx950-EXPERIMENT" 
 
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
   if (ctx && ctx->parent) ctx = ctx->parent;
-  return ctx ? err_slot(ctx->id).c_str() : g_create_error.c_str();
+  return ctx ? err_text(ctx->id) : g_create_error.c_str();
 }
 
 int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out) {
@@ -1176,7 +1210,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     if (b->p) (void)hipHostFree(b->p);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  t_errors.erase(ctx->id);
+  handle_gone(ctx->id);
   delete ctx;
 }
 
@@ -1807,10 +1841,11 @@ int tfhe_hip_load_reenc_key(tfhe_hip_ctx *ctx, const uint32_t *key) {
   return TFHE_HIP_OK;
 }
 
-int tfhe_hip_reenc_key_is_loaded(tfhe_hip_ctx *ctx) {
+int tfhe_hip_reenc_key_is_loaded(tfhe_hip_ctx *ctx) {  // 0 / 1, never an error code (no device call is made)
   if (!ctx) return 0;
-  ENTER(ctx);
-  return ctx->K->reenc_loaded ? 1 : 0;
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  std::lock_guard<FairMutex> lk(base->mu);
+  return ctx->own.reenc_loaded ? 1 : 0;
 }
 
 int tfhe_hip_batch_reencrypt_dev(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count, void *stream) {
@@ -1965,6 +2000,12 @@ int tfhe_hip_describe_dispatch(tfhe_hip_ctx *ctx, size_t count, char *buf, size_
   if (d.size() + 1 > buflen) return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_describe_dispatch: buffer too small");
   memcpy(buf, d.c_str(), d.size() + 1);
   return TFHE_HIP_OK;
+}
+
+const char *tfhe_hip_rounding_mode(const tfhe_hip_ctx *ctx) {
+  if (!ctx) return "none";
+  const tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  return base->fast_round ? "fast" : "general";
 }
 
 #ifdef TFHE_EXPERIMENT

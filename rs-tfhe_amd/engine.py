@@ -369,7 +369,7 @@ class Engine:
         self._chk(self._lib.tfhe_hip_load_reenc_key(self._ctx, _ptr(key)))
 
     def reenc_key_is_loaded(self) -> bool:
-        return bool(self._lib.tfhe_hip_reenc_key_is_loaded(self._ctx))
+        return self._lib.tfhe_hip_reenc_key_is_loaded(self._ctx) == 1  # 0 / 1; anything else is not "loaded"
 
     def batch_reencrypt(self, cts) -> np.ndarray:
         """proxy_reenc::reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510) over [count][n+1] host ciphertexts."""
@@ -404,12 +404,13 @@ class Engine:
         return out
 
     # -- device-resident path (torch CUDA tensors; enqueue only) ------------------
-    @staticmethod
-    def _stream_ptr(stream):
+    def _stream_ptr(self, stream):
         if stream is None:
             import torch
 
-            stream = torch.cuda.current_stream()
+            stream = torch.cuda.current_stream(self.device)  # of THIS engine's GPU, whatever torch's current device is
+        elif getattr(stream, "device", None) is not None and stream.device.index != self.device:
+            raise ValueError(f"stream lives on {stream.device}, the engine on cuda:{self.device}")
         # torch's default stream is the legacy null stream (handle 0); the C ABI reads NULL as "the
         # context's own stream", so name the null stream explicitly: hipStreamLegacy == (hipStream_t)1
         return C.c_void_p(stream.cuda_stream or 1)
@@ -527,6 +528,11 @@ class Engine:
 
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))
+
+    @property
+    def rounding_mode(self) -> str:
+        """"fast" / "general": the blind-rotation kernels' rounding of the external product (`tfhe_hip_rounding_mode`)."""
+        return self._lib.tfhe_hip_rounding_mode(self._ctx).decode()
 
     def describe_dispatch(self, count: int) -> str:
         """Which kernels a batch of `count` runs on (`tfhe_hip_describe_dispatch`), e.g.
@@ -759,13 +765,24 @@ class Pool:
             raise ValueError(f"device tensor lives on {t.device}, the home member on cuda:{self.devices[home]}")
         return p
 
-    _stream_ptr = staticmethod(Engine._stream_ptr)
+    def _stream_ptr(self, home: int, stream):
+        """The HOME member's stream: torch's current stream OF THAT DEVICE (the torch-current device may be another
+        GPU: a handle from there would be an invalid resource on the home GPU after the scatter was enqueued), or the
+        caller's stream, which must live on the home member's device."""
+        import torch
+
+        dev = self.devices[home]
+        if stream is None:
+            stream = torch.cuda.current_stream(dev)
+        elif getattr(stream, "device", None) is not None and stream.device.index != dev:
+            raise ValueError(f"stream lives on {stream.device}, the home member on cuda:{dev}")
+        return C.c_void_p(stream.cuda_stream or 1)
 
     def batch_gate_dev(self, gate: int, a, b, out, stream=None, home=None) -> None:
         h = self._home(home)
         count = self._dev_batch(h, a, b, out)
         self._chk(self._lib.tfhe_hip_pool_batch_gate_dev(self._h, h, int(gate), self._tp(h, a), self._tp(h, b), self._tp(h, out),
-                                                         count, self._stream_ptr(stream)))
+                                                         count, self._stream_ptr(h, stream)))
 
     def batch_gates_mixed_dev(self, gates, a, b, out, stream=None, keyswitch: bool = True, home=None) -> None:
         h = self._home(home)
@@ -776,7 +793,7 @@ class Pool:
             raise ValueError("one gate code per ciphertext")
         fn = self._lib.tfhe_hip_pool_batch_gates_mixed_dev if keyswitch else self._lib.tfhe_hip_pool_batch_gates_mixed_nks_dev
         self._chk(fn(self._h, h, C.c_void_p(gates.data_ptr()), self._tp(h, a), self._tp(h, b), self._tp(h, out), count,
-                     self._stream_ptr(stream)))
+                     self._stream_ptr(h, stream)))
 
     def batch_bootstrap_dev(self, cts, out, testvec=None, per_ct: bool = False, keyswitch: bool = True, stream=None,
                             home=None) -> None:
@@ -785,14 +802,14 @@ class Pool:
         if testvec is not None and testvec.numel() != (count if per_ct else 1) * 2 * N:
             raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
         self._chk(self._lib.tfhe_hip_pool_batch_bootstrap_dev(self._h, h, self._tp(h, cts), self._tp(h, testvec), int(per_ct),
-                                                              int(keyswitch), self._tp(h, out), count, self._stream_ptr(stream)))
+                                                              int(keyswitch), self._tp(h, out), count, self._stream_ptr(h, stream)))
 
     def batch_tlwe_lincomb_dev(self, ca: int, a, cb: int, b, cconst: int, out, stream=None, home=None) -> None:
         h = self._home(home)
         count = self._dev_batch(h, a, b, out)
         self._chk(self._lib.tfhe_hip_pool_batch_tlwe_lincomb_dev(
             self._h, h, ca & 0xFFFFFFFF, self._tp(h, a), cb & 0xFFFFFFFF, self._tp(h, b), cconst & 0xFFFFFFFF, self._tp(h, out),
-            count, self._stream_ptr(stream)))
+            count, self._stream_ptr(h, stream)))
 
     def batch_lincomb_bootstrap_dev(self, ca: int, a, cb: int, b, cconst: int, out, testvec=None, per_ct: bool = False,
                                     keyswitch: bool = True, stream=None, home=None) -> None:
@@ -802,13 +819,13 @@ class Pool:
             raise ValueError("test vector must be [2][N], or [count][2][N] with per_ct")
         self._chk(self._lib.tfhe_hip_pool_batch_lincomb_bootstrap_dev(
             self._h, h, ca & 0xFFFFFFFF, self._tp(h, a), cb & 0xFFFFFFFF, self._tp(h, b), cconst & 0xFFFFFFFF,
-            self._tp(h, testvec), int(per_ct), int(keyswitch), self._tp(h, out), count, self._stream_ptr(stream)))
+            self._tp(h, testvec), int(per_ct), int(keyswitch), self._tp(h, out), count, self._stream_ptr(h, stream)))
 
     def batch_mux_dev(self, a, b, c, out, naive: bool, stream=None, home=None) -> None:
         h = self._home(home)
         count = self._dev_batch(h, a, b, c, out)
         self._chk(self._lib.tfhe_hip_pool_batch_mux_dev(self._h, h, int(naive), self._tp(h, a), self._tp(h, b), self._tp(h, c),
-                                                        self._tp(h, out), count, self._stream_ptr(stream)))
+                                                        self._tp(h, out), count, self._stream_ptr(h, stream)))
 
     def batch_blind_rotate_dev(self, cts, out_trlwe, testvec=None, stream=None, home=None) -> None:
         h = self._home(home)
@@ -816,7 +833,7 @@ class Pool:
         if out_trlwe.numel() != count * 2 * N or (testvec is not None and testvec.numel() != 2 * N):
             raise ValueError("out_trlwe must be [count][2][N], testvec [2][N]")
         self._chk(self._lib.tfhe_hip_pool_batch_blind_rotate_dev(self._h, h, self._tp(h, cts), self._tp(h, testvec),
-                                                                 self._tp(h, out_trlwe), count, self._stream_ptr(stream)))
+                                                                 self._tp(h, out_trlwe), count, self._stream_ptr(h, stream)))
 
     def synchronize(self) -> None:
         """Drain every member's own stream (`tfhe_hip_pool_synchronize`); the home stream is the caller's."""

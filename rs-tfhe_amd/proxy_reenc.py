@@ -72,6 +72,8 @@ class ProxyReencryptionKey:
     zero, :311-313), base, t.  `reencrypt` keeps the key resident on the GPU in a key view of the shared context."""
 
     def __init__(self, params: SecurityParams, key_encryptions, basebit: int, t: int):
+        if params.n > 1024:  # (the key-switch kernels' row count is N = 1024: said here, not at the first reencrypt)
+            raise ValueError(f"proxy re-encryption on the GPU needs n <= 1024 ({params.name}: n = {params.n})")
         self.params = params
         self.basebit, self.t, self.base = int(basebit), int(t), 1 << int(basebit)
         self.key_encryptions = np.ascontiguousarray(key_encryptions, dtype=np.uint32).reshape(
@@ -141,9 +143,22 @@ class ProxyReencryptionKey:
         return self._view[1]
 
     def close(self) -> None:
-        if self._view is not None:
+        """Free the key's device memory (also on garbage collection, and at the end of a `with` block)."""
+        if getattr(self, "_view", None) is not None:
             self._view[1].close()
             self._view = None
+
+    def __enter__(self) -> "ProxyReencryptionKey":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reencrypt(self, cts, device: int = 0) -> np.ndarray:
         """reencrypt_tlwe_lv0 (proxy_reenc.rs:468-510) over [count][n+1] (or one [n+1]) ciphertexts."""

@@ -485,6 +485,117 @@ def test_extreme_parameter_shapes(O):
         R.Engine(SecurityParams("TOO_BIG", 0, 1280, 3, 6, 2, 9, 1e-5, 1e-8), 0)
 
 
+L1_EXACT_SHAPES = (  # (n, l, bgbit, basebit, t, seed)
+    (64, 1, 10, 5, 3, 54),    # general rounding (1 + 10 + 9 + 31 = 51 is not < 51) in the exact regime (|x| < 2^51)
+    (820, 1, 10, 5, 3, 55),   # SECURITY_UINT4's n, base-32 key switch
+    (300, 1, 9, 2, 8, 56),    # l = 1 on the FAST rounding path (50 < 51): k_blind_rotate<1, true>
+)
+
+
+def _edge_keys(O, n, l, bgbit, basebit, t, seed):
+    import rs_tfhe_amd as R
+    from rs_tfhe_amd.params import SecurityParams
+
+    op = O.Params(f"EDGE_{n}_{l}_{bgbit}", n, l, bgbit, basebit, t, 2.0e-5, 2.0e-8)
+    sk, ck = oracle_keys(O, op, seed=seed, with_time=True)
+    pp = SecurityParams(op.name, 0, n, l, bgbit, basebit, t, op.alpha_lv0, op.alpha_lv1)
+    pk = R.CloudKey(pp, ck.bootstrapping_key, ck.key_switching_key, ck.decomposition_offset, ck.blind_rotate_testvec)
+    return sk, ck, pp, pk
+
+
+@pytest.mark.parametrize("shape", L1_EXACT_SHAPES, ids=lambda s: f"n{s[0]}_l{s[1]}_bg{s[2]}")
+def test_l1_general_rounding_exact_regime_bit_exact(O, shape, monkeypatch):
+    """l = 1 where the f64 product is EXACT (bgbit = 10: 2 * 1024 * 512 * 2^31 = 2^51 < 2^52), so the reference's
+    `round() as i64 as u32` (klemsa.rs:145-146) has one right answer per word and any rounding slip shows: the
+    general-rounding instantiations k_blind_rotate<1, false>, k_blind_rotate_wide2<1, false>, k_blind_rotate_pair<1, false>
+    and k_external_product<1, false> -- which every reference parameter set with l = 1 runs, but only in the inexact
+    regime (bgbit >= 15), where tests can compare by tolerance alone -- word for word against the CPU path AND against
+    the exact integer product; (300, 1, 9) does the same for the FAST l = 1 instantiations."""
+    import rs_tfhe_amd as R
+
+    n, l, bgbit, basebit, t, seed = shape
+    sk, ck, pp, pk = _edge_keys(O, *shape)
+    rng = np.random.default_rng(seed)
+    cts = rng.integers(0, 2**32, (21, n + 1), dtype=np.uint64).astype(np.uint32)
+    cts2 = rng.integers(0, 2**32, (21, n + 1), dtype=np.uint64).astype(np.uint32)
+    want_rot = O.batch_blind_rotate(ck, cts)
+    want_boot = O.batch_bootstrap(ck, cts)
+    want_gate = O.batch_gate(ck, O.GATE_XOR, cts, cts2)
+    # the CPU path itself is exact here: its f64 blind rotation equals the exact-integer one
+    for i in (0, 20):
+        assert np.array_equal(want_rot[i], O.blind_rotate(ck, cts[i], exact=True))
+    trl = rng.integers(0, 2**32, (6, 2, N), dtype=np.uint64).astype(np.uint32)
+    idx = np.array([0, 1, n // 2, n - 1, 3 % n, 7 % n], np.int32)
+    want_ep = np.stack([O.external_product_exact(ck.bootstrapping_key_time[i], x, l, bgbit, ck.decomposition_offset) for i, x in zip(idx, trl)])
+    for name in BR_KERNEL_ENVS:
+        _with_br_kernel(monkeypatch, name)
+        eng = R.Engine(pp, 0)
+        eng.load_cloud_key(pk)
+        assert eng.rounding_mode == ("general" if bgbit == 10 else "fast")
+        assert f"blind_rotate={name}[0,21)" in eng.describe_dispatch(21)
+        assert np.array_equal(eng.batch_blind_rotate(cts), want_rot), (shape, name)
+        assert np.array_equal(eng.batch_bootstrap(cts), want_boot), (shape, name)
+        assert np.array_equal(eng.batch_gate(O.GATE_XOR, cts, cts2), want_gate), (shape, name)
+        assert np.array_equal(eng.batch_external_product(trl, idx), want_ep), (shape, name)  # 0 LSB vs the exact product
+        eng.close()
+
+
+def test_rounding_mutation_is_caught():
+    """The suite must NOTICE a one-LSB slip in the general rounding: the same l = 1 exact-regime test, run as a child
+    process against a mutation build of the library (csrc/experiment.hpp TFHE_ABL_ROUND_LSB: round_product<false> returns
+    one LSB too much on ~1/1024 of the words; `make -C rs-tfhe_amd/csrc mutation`, built by __graft_entry__.build()), has to
+    FAIL on the general-rounding shapes -- with assertion errors of that test, not for any other reason -- and still pass
+    on the FAST-path shape, which the mutation does not touch."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "rs-tfhe_amd", "libtfhe_v_round_lsb.so")
+    assert os.path.exists(lib), "mutation build missing: make -C rs-tfhe_amd/csrc mutation"
+    env = dict(os.environ, TFHE_HIP_LIB=lib, TFHE_HIP_ALLOW_EXPERIMENT="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_l1_general_rounding_exact_regime_bit_exact"], cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    out = p.stdout + p.stderr
+    assert p.returncode == 1, out[-3000:]
+    assert "2 failed, 1 passed" in out, out[-3000:]
+    for shape_id in ("n64_l1_bg10", "n820_l1_bg10"):
+        assert f"FAILED tests/test_gpu_parity.py::test_l1_general_rounding_exact_regime_bit_exact[{shape_id}] - AssertionError" in out, out[-3000:]
+    assert "ImportError" not in out and "Error loading" not in out
+
+
+INEXACT_SETS = ["SECURITY_UINT2", "SECURITY_UINT3", "SECURITY_UINT4", "SECURITY_UINT5", "SECURITY_UINT6", "SECURITY_UINT7", "SECURITY_UINT8"]
+
+
+@pytest.mark.parametrize("setname", INEXACT_SETS)
+def test_external_product_error_relative_to_the_cpu_path(O, setname):
+    """Where the f64 product is NOT exact (bgbit >= 15) the reference's own result carries an f64 error (~2^7
+    LSB at bgbit = 22).  Instead of a fixed bound: on the same inputs, the GPU's error against the exact integer product
+    must be no more than twice the CPU path's (klemsa.rs:119-150 restated in the oracle) -- per external product, 24
+    products per set, every reference set with an inexact product."""
+    import rs_tfhe_amd as R
+
+    op = getattr(O, setname)
+    sk, ck = oracle_keys(O, op, seed=88, with_time=True)
+    pk = _cloud_key(ck)
+    eng = R.bootstrap.engine_for(pk.params, 0)
+    eng.ensure_key(pk)
+    assert eng.rounding_mode == "general"
+    rng = np.random.default_rng(88)
+    count = 24
+    idx = rng.integers(0, op.n, count).astype(np.int32)
+    trl = rng.integers(0, 2**32, (count, 2, N), dtype=np.uint64).astype(np.uint32)
+    got = eng.batch_external_product(trl, idx)
+    worst = 0.0
+    for i, x, g in zip(idx, trl, got):
+        exact = O.external_product_exact(ck.bootstrapping_key_time[i], x, op.l, op.bgbit, ck.decomposition_offset)
+        cpu = O.external_product_fft(ck.bootstrapping_key[i], x, op.l, op.bgbit, ck.decomposition_offset)
+        e_gpu, e_cpu = signed_diff(g, exact), signed_diff(cpu, exact)
+        assert e_gpu <= 2 * max(e_cpu, 1), (setname, int(i), e_gpu, e_cpu)
+        worst = max(worst, e_gpu / max(e_cpu, 1))
+    assert worst <= 2.0
+
+
 def test_full_size_pbs_uint4(O, keys_uint4):
     """BASELINE configs[3] at full size: 65,536 DISTINCT ciphertexts through LutBootstrap::bootstrap_lut (m = 16,
     f = x^2 mod 16), SECURITY_UINT4, device-resident.  Every output decrypts to f(message); the same input at another
@@ -1679,7 +1790,7 @@ def _run_bench(extra_args, env_extra, timeout=900):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.update(env_extra)
-    env.setdefault("MASTER_PORT", "29547")
+    env.pop("MASTER_PORT", None)  # bench.py picks a free port for its torchrun child
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra_args, cwd=root, env=env,
                        capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.returncode, p.stdout[-2000:], p.stderr[-4000:])
@@ -1702,8 +1813,24 @@ def test_bench_two_ranks_share_one_gpu():
 def test_bench_two_ranks_mixed_circuit_80bit():
     """The same with BASELINE configs[4]'s gate mix (half Gates::mux, half hom_xor) at SECURITY_80_BIT."""
     d = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "2048", "--no-cpu-baseline",
-                    "--gate", "mixed", "--params", "SECURITY_80_BIT"], {"BENCH_SHARE_GPU": "1", "MASTER_PORT": "29549"})
+                    "--gate", "mixed", "--params", "SECURITY_80_BIT"], {"BENCH_SHARE_GPU": "1"})
     assert d["n_gpus"] == 2 and d["decrypt_ok"] is True and "SECURITY_80_BIT" in d["metric"]
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """`bench.py --gpus 8`, the N = 8 branch the driver's scaling sweep runs, end to end on this box's one GPU (eight
+    ranks, BENCH_SHARE_GPU=1): no MASTER_PORT given, so the torchrun child gets a port that is free now; the line carries
+    every rank's own time for the steps, its kernels' launch times and the key broadcast's duration."""
+    for extra in ([], ["--gate", "mixed", "--params", "SECURITY_80_BIT"]):
+        d = _run_bench(["--gpus", "8", "--steps", "1", "--warmup", "0", "--batch", "1024", "--no-cpu-baseline"] + extra,
+                       {"BENCH_SHARE_GPU": "1"})
+        assert d["n_gpus"] == 8 and d["decrypt_ok"] is True and d["scaling"] == "weak"
+        assert d["config"]["global_batch"] == 8192 and d["value"] > 0
+        pr = d["per_rank"]
+        assert all(len(pr[k]) == 8 for k in ("ms_per_step", "blind_rotate_ms", "key_switch_ms", "shader_mhz", "key_broadcast_s"))
+        assert d["ms_per_step_max_rank"] == max(pr["ms_per_step"]) and d["ms_per_step_min_rank"] > 0
+        assert d["ms_per_step"] >= d["ms_per_step_max_rank"] - 0.01  # the line's time is the max over ranks
+        assert d["key_broadcast_s"] > 0 and d["key_broadcast_backend"] == "gloo"
 
 
 def test_bench_pool_two_members_pinned_and_pageable():

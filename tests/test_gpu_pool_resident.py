@@ -303,3 +303,143 @@ def test_pool_views_share_the_parents_lock_and_communicator(O, eng128, keys128, 
     view._h = None
     view._parent = None
     lib.tfhe_hip_pool_destroy(h_view)
+
+
+# ---- the 8-GPU workloads of BASELINE.json at their GLOBAL size, through the one handle a caller would use ---------------
+def _spread_per_shard(pool, count, world, per_shard=256, edge=4):
+    """Indices to hold against the CPU path: `per_shard` spread over every shard of the order-preserving cut plus the
+    first and last `edge` of each (a wrong boundary, a swapped shard or a short transfer shows at the edges first)."""
+    idx = []
+    for r in range(world):
+        lo, hi = pool.shard(count, r)
+        idx.append(np.r_[lo:lo + edge, np.linspace(lo, hi - 1, per_shard).astype(np.int64), hi - edge:hi])
+    return np.unique(np.concatenate(idx))
+
+
+def _encrypt_chunks(sk, bits, seed, chunk=65536):
+    """[len(bits)][n+1] fresh encryptions, generated chunk by chunk (distinct seeds) into one array."""
+    out = np.empty((len(bits), sk.params.n + 1), np.uint32)
+    for i, lo in enumerate(range(0, len(bits), chunk)):
+        out[lo:lo + chunk] = sk.encrypt_bool(bits[lo:lo + chunk], seed + i)
+    return out
+
+
+def _decrypt_all(sk, out, chunk=131072):
+    n = sk.params.n
+    key = sk.key_lv0.astype(np.uint32)[None, :]
+    res = np.empty(len(out), bool)
+    for lo in range(0, len(out), chunk):
+        o = out[lo:lo + chunk]
+        res[lo:lo + chunk] = (o[:, n] - (o[:, :n] * key).sum(axis=1, dtype=np.uint32)).view(np.int32) >= 0
+    return res
+
+
+def test_configs2_global_batch_through_eight_member_pool(O, eng128, keys128):
+    """BASELINE configs[2] at its GLOBAL size: 524,288 hom_nand at SECURITY_128_BIT on 524,288 distinct ciphertext
+    pairs, resident on member 0's GPU, through ONE `tfhe_hip_pool_batch_gate_dev` call on an eight-member pool
+    (devices = [0] * 8: the box has one GPU, so the seven remote shards travel by peer copies -- the staging buffers,
+    shard arithmetic, events and order-preserving gather are the ones eight GPUs run; only the physical xGMI links are
+    not exercised).  Bar: every output decrypts to nand(a, b); >= 256 outputs spread over EVERY shard plus each shard's
+    first and last four equal the CPU path word for word (gates.rs:357-383: results in input order)."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pool = R.Pool(eng128.params, [0] * 8)
+    pool.load_cloud_key(_cloud_key(ck))
+    B = 524288
+    assert pool.members_for(B) == 8
+    rng = np.random.default_rng(9800)
+    bits_a, bits_b = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    ca, cb = _encrypt_chunks(sk, bits_a, 9801), _encrypt_chunks(sk, bits_b, 9901)
+    ta, tb = _dev(ca), _dev(cb)
+    to = torch.full_like(ta, 0x5A5A5A5A)
+    pool.set_profiling(True)
+    pool.transfer_times()
+    pool.batch_gate_dev(O.GATE_NAND, ta, tb, to, home=0)
+    pool.synchronize()
+    torch.cuda.synchronize()
+    tt = pool.transfer_times()
+    pool.set_profiling(False)
+    assert pool.data_transport == "peer-copy"
+    lo0, hi0 = pool.shard(B, 0)
+    moved = B - (hi0 - lo0)
+    assert tt["calls"] == 1 and tt["scatter_bytes"] == 2 * moved * 701 * 4 and tt["gather_bytes"] == moved * 701 * 4
+    out = _host(to)
+    del ta, tb
+    assert np.array_equal(_decrypt_all(sk, out), ~(bits_a & bits_b))
+    idx = _spread_per_shard(pool, B, 8)
+    assert len(idx) >= 8 * 256
+    assert np.array_equal(out[idx], O.batch_gate(ck, O.GATE_NAND, ca[idx], cb[idx]))
+    pool.close()
+
+
+def test_every_home_member_of_an_eight_member_pool(O, eng128, keys128):
+    """Shard r runs on member (home + r) mod 8: every member 0..7 as HOME once, on a ragged batch cut eight ways (and on
+    one cut three ways), each against the single context word for word; the first and last result of every shard also
+    against the CPU path."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    pool = R.Pool(eng128.params, [0] * 8)
+    pool.load_cloud_key(_cloud_key(ck))
+    rng = np.random.default_rng(9850)
+    for count in (8 * 300 + 5, 700):
+        A, B = rng.integers(0, 2, count).astype(bool), rng.integers(0, 2, count).astype(bool)
+        ca, cb = sk.encrypt_bool(A, 9851 + count), sk.encrypt_bool(B, 9852 + count)
+        ta, tb = _dev(ca), _dev(cb)
+        want = torch.empty_like(ta)
+        eng128.batch_gate_dev(O.GATE_NAND, ta, tb, want)
+        torch.cuda.synchronize()
+        w = _host(want)
+        world = pool.members_for(count)
+        assert world == (8 if count > 2048 else 3)
+        edges = np.unique(np.concatenate([np.r_[pool.shard(count, r)[0], pool.shard(count, r)[1] - 1] for r in range(world)]))
+        assert np.array_equal(w[edges], O.batch_gate(ck, O.GATE_NAND, ca[edges], cb[edges]))
+        for home in range(8):
+            got = torch.full_like(ta, 0x5A5A5A5A)
+            pool.batch_gate_dev(O.GATE_NAND, ta, tb, got, home=home)
+            pool.synchronize()
+            torch.cuda.synchronize()
+            assert np.array_equal(_host(got), w), (count, home)
+    pool.close()
+
+
+def test_configs4_global_batch_through_eight_member_pool(O, keys80):
+    """BASELINE configs[4] at its GLOBAL size: 2^20 gates at SECURITY_80_BIT, half `Gates::mux` (the reference's formula,
+    gates.rs:157-183, quirk Q5) and half hom_xor, all 5 x 524,288 input ciphertexts distinct and resident on member 0's
+    GPU, as ONE circuit level through ONE eight-member pool handle (`circuit.mux_and_gates_dev`: two pool calls of 2^20
+    items each, cut eight ways).  Bar: the xor half decrypts; >= 256 mux and >= 256 xor outputs spread over every shard of
+    the second call's cut (plus shard edges) equal the CPU path word for word."""
+    import torch
+
+    import rs_tfhe_amd as R
+
+    sk, ck = keys80
+    pk = _cloud_key(ck)
+    pool = R.Pool(pk.params, [0] * 8)
+    pool.load_cloud_key(pk)
+    M = X = 524288
+    rng = np.random.default_rng(9900)
+    bits = rng.integers(0, 2, (5, M)).astype(bool)
+    a, b, c, xa, xb = (_encrypt_chunks(sk, bits[w], 10000 + 100 * w) for w in range(5))
+    ta, tb, tc, txa, txb = (_dev(x) for x in (a, b, c, xa, xb))
+    codes = torch.full((X,), R.engine.XOR, dtype=torch.uint8, device="cuda:0")
+    mo, xo = R.circuit.mux_and_gates_dev(pool, ta, tb, tc, codes, txa, txb)
+    pool.synchronize()
+    torch.cuda.synchronize()
+    assert pool.data_transport == "peer-copy"
+    mux, xor = _host(mo).copy(), _host(xo).copy()
+    del ta, tb, tc, txa, txb, mo, xo
+    assert np.array_equal(_decrypt_all(sk, xor), bits[3] ^ bits[4])
+    # the second pool call holds [M mux | X xor] as ONE batch of M + X items: its eight shards are halves 0-3 (mux) and
+    # 4-7 (xor); take the spread over that cut
+    idx = _spread_per_shard(pool, M + X, 8)
+    im, ix = idx[idx < M], idx[idx >= M] - M
+    assert len(im) >= 4 * 256 and len(ix) >= 4 * 256
+    assert np.array_equal(mux[im], O.batch_mux(ck, a[im], b[im], c[im], naive=False))
+    assert np.array_equal(xor[ix], O.batch_gate(ck, O.GATE_XOR, xa[ix], xb[ix]))
+    pool.close()

@@ -389,3 +389,24 @@ def test_measured_tables_are_generated_from_the_committed_bench_lines():
     hp = mod.headline_paragraph()
     for doc in ("README.md", "DESIGN.md"):
         assert hp in open(os.path.join(ROOT, doc)).read(), f"{doc}: run `python3 profiles/readme_bench.py --install`"
+
+
+def test_bench_picks_a_free_rendezvous_port():
+    """bench.py's torchrun child gets a port that is free at launch (the driver's 1 -> 8 sweep starts bench.py four times
+    in a row on one node; a fixed port can meet the previous run's lingering listener)."""
+    import socket
+
+    import bench
+
+    held = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    held.bind(("127.0.0.1", 0))
+    held.listen(1)
+    try:
+        ports = {bench.free_port() for _ in range(8)}
+        assert held.getsockname()[1] not in ports and all(1024 < p < 65536 for p in ports)
+        for p in ports:  # and each can be bound right away
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+                s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                s.bind(("127.0.0.1", p))
+    finally:
+        held.close()
