@@ -559,8 +559,9 @@ def test_rounding_mutation_is_caught():
     out = p.stdout + p.stderr
     assert p.returncode == 1, out[-3000:]
     assert "2 failed, 1 passed" in out, out[-3000:]
-    for shape_id in ("n64_l1_bg10", "n820_l1_bg10"):
-        assert f"FAILED tests/test_gpu_parity.py::test_l1_general_rounding_exact_regime_bit_exact[{shape_id}] - AssertionError" in out, out[-3000:]
+    for shape_id, shape in (("n64_l1_bg10", "(64, 1, 10, 5, 3, 54)"), ("n820_l1_bg10", "(820, 1, 10, 5, 3, 55)")):
+        assert f"FAILED tests/test_gpu_parity.py::test_l1_general_rounding_exact_regime_bit_exact[{shape_id}]" in out, out[-3000:]
+        assert f"AssertionError: ({shape}, 'single')" in out, out[-3000:]  # the first kernel tried, on its first comparison
     assert "ImportError" not in out and "Error loading" not in out
 
 
