@@ -1842,3 +1842,22 @@ def test_bench_pool_two_members_pinned_and_pageable():
         d = _run_bench(["--pool-devices", "0,0", "--steps", "1", "--warmup", "1", "--batch", "2048"] + extra, {})
         assert d["devices"] == [0, 0] and d["decrypt_ok"] is True and d["batch_total"] == 4096
         assert d["host_memory"].startswith("pinned" if extra else "pageable")
+
+
+def test_single_gate_latency_warm_and_after_idle(O, eng128, keys128):
+    """BASELINE configs[0] through the GPU: ONE `Gates::nand`-shaped call with host buffers (what criterion's `gate_nand`
+    times on the CPU, benches/gate_benchmarks.rs:12-20), as bench.py measures it -- median of back-to-back calls, and of
+    calls that each follow an idle gap.  Measured on MI355X boxes: 2.18 ms back to back (2.15 of it in the two kernels),
+    2.2 after 10 ms, 2.3 after 1 s (the kernels run at 2.16: the extra is the host side waking up), 2.7 after 10 s (the
+    kernels 2.56: the shader clock ramps).  The bounds leave room for the slowest box seen (+6 %) and a noisy host."""
+    import bench
+
+    sk, ck = keys128
+    ca = sk.encrypt_bool(np.array([1, 0, 1, 1, 0, 0, 1, 0], bool), 7001)
+    cb = sk.encrypt_bool(np.array([1, 1, 0, 1, 0, 1, 0, 0], bool), 7002)
+    lat = bench.single_gate_latency(eng128, O.GATE_NAND, ca, cb, schedule=((0.0, 50), (0.010, 20), (1.0, 3)))
+    warm, idle10ms, idle1s = lat["0s"], lat["0.01s"], lat["1s"]
+    assert warm["wall_ms_median"] < 2.6, lat
+    assert warm["wall_ms_median"] - warm["kernels_ms_median"] < 0.25, lat  # copies + launches + the synchronise
+    assert idle10ms["wall_ms_median"] < 2.8 and idle1s["wall_ms_median"] < 4.0, lat
+    assert np.array_equal(eng128.batch_gate(O.GATE_NAND, ca, cb), O.batch_gate(ck, O.GATE_NAND, ca, cb))
