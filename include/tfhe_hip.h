@@ -520,7 +520,9 @@ const char *tfhe_hip_pool_data_transport(const tfhe_hip_pool *pool);
  * Each moved shard is bracketed on the member's stream (the receiver of a scatter, the sender of a gather; a
  * gather's bracket opens after the member's compute); on the RCCL path the call's group is bracketed on the home
  * stream too, and a shard's time is the SHORTER of the two: a transfer starts when both ends have reached it, so the
- * end that arrived last brackets the transfer alone and the other one also brackets its wait for the peer.
+ * end that arrived last brackets the transfer alone and the other one also brackets its wait for the peer.  (When both
+ * brackets live on one device -- a self send / receive -- their events are comparable and the time is exact: from the
+ * later arrival to the later completion.)
  * comm_create_ms / key_replication_ms are host wall-clock set-up costs and are NOT reset by reading: the creation of
  * the pool's persistent communicator (0 when it has none) and the last replication of a cloud key to the members. */
 typedef struct tfhe_hip_pool_transfer_times {

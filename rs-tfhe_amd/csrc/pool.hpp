@@ -1023,17 +1023,38 @@ int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *p, tfhe_hip_pool_transfer_ti
   };
   std::vector<double> home_ms(root->ev_home.size(), -1.0);
   for (size_t i = 0; i < root->ev_home.size(); ++i) home_ms[i] = elapsed(root->ev_home[i]);
+  // between(x, y): ms from event x to event y on ONE device (negative when y fired first), -1e30 if not measurable
+  auto between = [&](hipEvent_t x, hipEvent_t y) -> double {
+    float ms = 0.f;
+    if (hipEventSynchronize(x) == hipSuccess && hipEventSynchronize(y) == hipSuccess && hipEventElapsedTime(&ms, x, y) == hipSuccess)
+      return (double)ms;
+    (void)hipGetLastError();
+    return -1e30;
+  };
   auto drain = [&](std::vector<tfhe_hip_pool::Timed> &v, double &sum, double &mx) {
     for (auto &t : v) {
       double ms = elapsed(t);
-      // RCCL path: the shorter of the member-side and the home-side bracket (see tfhe_hip_pool::Timed)
-      if (t.home_ix >= 0 && (size_t)t.home_ix < home_ms.size() && home_ms[(size_t)t.home_ix] >= 0 &&
-          (ms < 0 || home_ms[(size_t)t.home_ix] < ms))
-        ms = home_ms[(size_t)t.home_ix];
+      if (t.home_ix >= 0 && (size_t)t.home_ix < home_ms.size()) {
+        tfhe_hip_pool::Timed &h = root->ev_home[(size_t)t.home_ix];
+        const bool same_device = root->ctxs[(size_t)h.member]->device == root->ctxs[(size_t)t.member]->device;
+        const double ab = same_device ? between(t.a, h.a) : -1e30, bb = same_device ? between(t.b, h.b) : -1e30;
+        if (ab > -1e29 && bb > -1e29) {
+          // both brackets on ONE device (a pool that repeats a device, the self send / receive of the plumbing test): the
+          // events are comparable, so the transfer is measured exactly -- from the moment the LATER end arrived to the
+          // moment the later end finished (a self copy runs inside only one of the two RCCL kernels)
+          const double span = between(ab >= 0 ? h.a : t.a, bb >= 0 ? h.b : t.b);
+          if (span > -1e29) ms = span;
+        } else if (home_ms[(size_t)t.home_ix] >= 0 && (ms < 0 || home_ms[(size_t)t.home_ix] < ms)) {
+          // different devices: event times are not comparable; the shorter bracket (see tfhe_hip_pool::Timed)
+          ms = home_ms[(size_t)t.home_ix];
+        }
+      }
       if (ms >= 0) {
         sum += ms;
         if (ms > mx) mx = ms;
       }
+    }
+    for (auto &t : v) {
       (void)hipEventDestroy(t.a);
       (void)hipEventDestroy(t.b);
     }
