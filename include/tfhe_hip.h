@@ -99,7 +99,9 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx);
 /* Text of the CALLING THREAD's last error on this context (or of its last failed create when ctx == NULL).
  * Never NULL.  The text is kept per (thread, handle): threads that share a context (`Send + Sync`,
  * src/bootstrap/mod.rs:23) each read their own failure, and the pointer stays valid until the same thread's next
- * failing call on the same handle.  tfhe_hip_pool_last_error follows the same rule. */
+ * failing call on the same handle.  A thread that has not failed on the handle reads "" (it never sees another
+ * thread's text, and reading stores nothing); a thread's table of texts is bounded: entries of destroyed handles are
+ * dropped once it holds 64.  tfhe_hip_pool_last_error follows the same rule. */
 const char *tfhe_hip_last_error(const tfhe_hip_ctx *ctx);
 
 /* ---- key views: several resident cloud keys on ONE context -----------------------------------------
