@@ -264,3 +264,41 @@ def test_crate_patch_applies_to_the_reference(tmp_path):
     assert "pub fn rows(&self)" in trgsw and "crate::gates_hip::batch_blind_rotate_hip(srcs, cloud_key)" in trgsw
     for rel in ("src/bootstrap/hip.rs", "src/gates_hip.rs", "src/proxy_reenc_hip.rs", "tests/hip_gates.rs"):
         assert (crate / rel).exists(), rel
+
+
+RUST_STD_METHODS = {  # methods of std types the binding calls (slices, iterators, Option/Result, Mutex, OnceLock, CStr, str, pointers)
+    "all", "as_mut_ptr", "as_ptr", "as_ref", "borrow", "borrow_mut", "chunks_exact", "clone", "collect", "copy_from_slice", "drain",
+    "enumerate", "expect", "extend_from_slice", "fill_bytes", "filter", "find", "for_each", "get_or_init", "is_null", "is_power_of_two",
+    "iter", "iter_mut", "len", "lock", "map", "map_or", "min_by_key", "parse", "pop", "position", "push", "remove", "split", "to_str",
+    "to_string_lossy", "trailing_zeros", "trim", "unwrap", "unwrap_or", "with", "wrapping_mul", "zip", "to_bits", "get", "is_empty",
+}
+
+
+def test_rust_methods_and_fields_exist():
+    """A typo guard in place of the compiler: every `.method(` the files under rust/ call is a `fn` of the crate (the
+    reference tree or the binding itself) or a known std method, and every `.field` they read is a field of some struct of
+    the crate or the binding.  Needs the reference tree."""
+    import glob
+
+    import pytest
+
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("reference tree not present")
+    ours = _rust_sources() + [os.path.join(ROOT, "rust", "tests", "hip_gates.rs")]
+    crate = glob.glob("/root/reference/src/**/*.rs", recursive=True)
+    fns, fields = set(), set()
+    for f in ours + crate:
+        text = open(f).read()
+        fns |= set(re.findall(r"\bfn\s+(\w+)", text))
+        for body in re.findall(r"\bstruct\s+\w+[^{;]*\{(.*?)\n\}", text, flags=re.S):
+            fields |= set(re.findall(r"(?:pub\s+)?(\w+)\s*:", body))
+    problems = []
+    for f in ours:
+        text = re.sub(r"//[^\n]*", "", open(f).read())
+        text = re.sub(r'"(?:[^"\\]|\\.)*"', '""', text)  # string literals out of the way
+        for name in sorted(set(re.findall(r"\.(\w+)\s*\(", text)) - fns - RUST_STD_METHODS):
+            problems.append(f"{os.path.relpath(f, ROOT)}: method `.{name}()` is neither a fn of the crate nor a known std method")
+        for name in sorted(set(re.findall(r"\.([a-z_]\w*)\b(?!\s*[(:!])", text)) - fields - fns - {"unsafe", "gen", "await"}):
+            if not name[0].isdigit():
+                problems.append(f"{os.path.relpath(f, ROOT)}: field `.{name}` is not a field of any struct of the crate or the binding")
+    assert not problems, "\n".join(problems)
