@@ -10,6 +10,7 @@
 //! MI355X bootstrap strategies: blind rotate + sample extract + key switch on the GPU(s).
 use crate::bootstrap::Bootstrap;
 use crate::key::CloudKey;
+#[cfg(feature = "lut-bootstrap")]
 use crate::lut::LookupTable;
 use crate::{params, trlwe};
 use crate::utils::Ciphertext;
@@ -362,7 +363,10 @@ impl Bootstrap for HipBootstrap {
 }
 
 /// src/bootstrap/lut.rs:24-126 on the GPU: the LUT's polynomial is the test vector of the blind rotation.
+/// (Everything from here on needs the crate's `lut-bootstrap` feature, as `bootstrap::lut` itself does.)
+#[cfg(feature = "lut-bootstrap")]
 pub struct HipLutBootstrap { engine: std::sync::Arc<HipEngine> }
+#[cfg(feature = "lut-bootstrap")]
 impl HipLutBootstrap {
     /// mirrors `LutBootstrap::new()` (lut.rs:29-35): the process-wide engine
     pub fn new() -> Self { HipLutBootstrap { engine: default_engine() } }
@@ -381,7 +385,9 @@ impl HipLutBootstrap {
         self.engine.batch_bootstrap(cts, Some(&lut.poly), true, cloud_key)
     }
 }
+#[cfg(feature = "lut-bootstrap")]
 impl Default for HipLutBootstrap { fn default() -> Self { Self::new() } }
+#[cfg(feature = "lut-bootstrap")]
 impl Bootstrap for HipLutBootstrap {
     fn bootstrap(&self, ctxt: &Ciphertext, cloud_key: &CloudKey) -> Ciphertext {     // lut.rs:108-111: identity, m = 2
         self.bootstrap_func(ctxt, |x| x, 2, cloud_key)

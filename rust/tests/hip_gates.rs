@@ -16,6 +16,7 @@ use rs_tfhe::bootstrap::{default_bootstrap, Bootstrap};
 use rs_tfhe::gates::{self, Gates};
 use rs_tfhe::gates_hip;
 use rs_tfhe::key::{CloudKey, SecretKey};
+use rs_tfhe::parallel::default_railgun;
 use rs_tfhe::utils::Ciphertext;
 use rs_tfhe::{params, tlwe, trgsw, trlwe};
 
@@ -151,14 +152,14 @@ fn test_batch_gates_equal_the_cpu_functions() {
     let plains: Vec<(bool, bool)> = (0..600).map(|_| (rng.gen::<bool>(), rng.gen::<bool>())).collect();
     let inputs: Vec<(Ciphertext, Ciphertext)> = plains.iter().map(|&(a, b)| (enc(a, &key), enc(b, &key))).collect();
     // the CPU side: the reference's own `_with_railgun` bodies (gates.rs:357-547), which the patch leaves untouched
-    let rg = rs_tfhe::parallel::default_railgun;
+    // (non-capturing closures, so that they coerce to `fn` pointers)
     let cases: [(BatchFn, BatchFn, fn(bool, bool) -> bool); 6] = [
-        (gates_hip::batch_nand_hip, |i, k| gates::batch_nand_with_railgun(i, k, rg()), |a, b| !(a & b)),
-        (gates_hip::batch_and_hip, |i, k| gates::batch_and_with_railgun(i, k, rg()), |a, b| a & b),
-        (gates_hip::batch_or_hip, |i, k| gates::batch_or_with_railgun(i, k, rg()), |a, b| a | b),
-        (gates_hip::batch_xor_hip, |i, k| gates::batch_xor_with_railgun(i, k, rg()), |a, b| a ^ b),
-        (gates_hip::batch_nor_hip, |i, k| gates::batch_nor_with_railgun(i, k, rg()), |a, b| !(a | b)),
-        (gates_hip::batch_xnor_hip, |i, k| gates::batch_xnor_with_railgun(i, k, rg()), |a, b| a ^ b),   // gates.rs:575: the reference's xnor is xor
+        (gates_hip::batch_nand_hip, |i, k| gates::batch_nand_with_railgun(i, k, default_railgun()), |a, b| !(a & b)),
+        (gates_hip::batch_and_hip, |i, k| gates::batch_and_with_railgun(i, k, default_railgun()), |a, b| a & b),
+        (gates_hip::batch_or_hip, |i, k| gates::batch_or_with_railgun(i, k, default_railgun()), |a, b| a | b),
+        (gates_hip::batch_xor_hip, |i, k| gates::batch_xor_with_railgun(i, k, default_railgun()), |a, b| a ^ b),
+        (gates_hip::batch_nor_hip, |i, k| gates::batch_nor_with_railgun(i, k, default_railgun()), |a, b| !(a | b)),
+        (gates_hip::batch_xnor_hip, |i, k| gates::batch_xnor_with_railgun(i, k, default_railgun()), |a, b| a ^ b),   // gates.rs:575: the reference's xnor is xor
     ];
     for (gpu_fn, cpu_fn, truth) in cases {
         let gpu = gpu_fn(&inputs, &cloud_key);
