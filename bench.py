@@ -300,7 +300,7 @@ def key_switch_roofline(P, per_launch, ks_ms, ks_clk, pm, batch, plan=""):
     return out
 
 
-def single_gate_latency(eng, gate, ca, cb, schedule=((0.0, 60), (0.010, 50), (1.0, 8), (10.0, 2))):
+def single_gate_latency(eng, gate, ca, cb, schedule=((0.0, 60), (0.010, 50), (1.0, 5), (10.0, 1))):
     """BASELINE configs[0] through the GPU path: ONE `Gates::nand`-shaped call (host buffers in and out: two pageable
     H2D copies, the latency kernels, one D2H copy, one stream synchronise), which is what the reference's criterion
     `gate_nand` times on the CPU (benches/gate_benchmarks.rs:12-20).  A caller's gates do not arrive back to back, and
@@ -332,7 +332,7 @@ def single_gate_latency(eng, gate, ca, cb, schedule=((0.0, 60), (0.010, 50), (1.
             wall.append((time.perf_counter() - t1) * 1e3)
         eng.kernel_times()
         eng.set_profiling(True)
-        for _ in range(min(reps, 8)):
+        for _ in range(min(reps, 8 if gap < 1.0 else 3)):  # (the kernel-time pass sleeps too: keep the whole probe near 30 s)
             i = k % len(ca)
             k += 1
             if gap:
