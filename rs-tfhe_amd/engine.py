@@ -73,6 +73,11 @@ def pinned_copy(a) -> np.ndarray:
     return out
 
 
+def device_count() -> int:
+    """GPUs this process can open (`tfhe_hip_device_count`): what `Pool(params, range(device_count()))` spans."""
+    return int(_capi.lib().tfhe_hip_device_count())
+
+
 class Engine:
     """Owns a tfhe_hip_ctx.  Host arrays are numpy uint32; *_dev methods take
     torch CUDA tensors (int32 storage of the u32 words) and only enqueue work."""

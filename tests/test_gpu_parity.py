@@ -1439,6 +1439,23 @@ def test_golden_toy_instance(golden):
 
 
 # ---- edge cases and error behaviour ------------------------------------------------------------
+def test_device_count_and_all_devices_pool(O, eng128, keys128):
+    """`tfhe_hip_device_count` is what a host binding builds "all GPUs of the node" from (rust `default_engine()`,
+    the counterpart of Rayon's one-worker-per-CPU default, rayon_impl.rs:15-27): a pool over range(count) bootstraps."""
+    import rs_tfhe_amd as R
+
+    sk, ck = keys128
+    n = R.engine.device_count()
+    assert n >= 1 and n == __import__("torch").cuda.device_count()
+    pool = R.Pool(eng128.params, list(range(n)))
+    pool.load_cloud_key(_cloud_key(ck))
+    bits = np.array([1, 0, 1, 1, 0], bool)
+    ct = sk.encrypt_bool(bits, 8101)
+    out = pool.batch_gate(O.GATE_NAND, ct, ct)
+    assert np.array_equal(out, O.batch_gate(ck, O.GATE_NAND, ct, ct)) and np.array_equal(sk.decrypt_bool(out), ~bits)
+    pool.close()
+
+
 def test_edge_cases_and_errors(O, eng128, keys128):
     import rs_tfhe_amd as R
     from rs_tfhe_amd import _capi
