@@ -1185,6 +1185,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
       if (base->stream) (void)hipStreamSynchronize(base->stream);
       free_key(ctx->own);
       last_of_dying = --base->views == 0 && base->dying;
+      handle_gone(ctx->id);  // (a view's id keys no text -- its errors are its parent's -- but it is registered as live)
       delete ctx;
     }
     if (last_of_dying) tfhe_hip_ctx_destroy(base);  // the parent was destroyed first: it has waited for its views
