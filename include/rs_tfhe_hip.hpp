@@ -562,8 +562,23 @@ struct Encoder {  // encoder.rs:13-115
   bool decode_bool(Torus v) const { return decode(v) != 0; }
 };
 
-struct LookupTable {  // lookup_table.rs:16-19
+struct LookupTable {  // lookup_table.rs:16-68
   TRLWELv1 poly;
+  LookupTable() = default;
+  static LookupTable from_poly(const TRLWELv1 &p) {  // :33-35
+    LookupTable t;
+    t.poly = p;
+    return t;
+  }
+  void copy_from(const LookupTable &other) { poly = other.poly; }  // :51-54
+  void clear() { poly = TRLWELv1(); }                              // :57-61
+  bool is_empty() const {                                          // :64-68
+    for (Torus v : poly.a)
+      if (v) return false;
+    for (Torus v : poly.b)
+      if (v) return false;
+    return true;
+  }
 };
 
 class Generator {  // generator.rs:15-259
@@ -577,8 +592,21 @@ class Generator {  // generator.rs:15-259
   LookupTable generate_lookup_table(const std::function<size_t(size_t)> &f) const {  // :66-137
     return assemble([&](size_t x) { return encoder_.encode(f(x)); });
   }
-  LookupTable generate_lookup_table_full(const std::function<Torus(size_t)> &f) const {  // :146-203
+  void generate_lookup_table_assign(const std::function<size_t(size_t)> &f, LookupTable &lut_out) const {  // :89-137
+    lut_out = generate_lookup_table(f);
+  }
+  LookupTable generate_lookup_table_full(const std::function<Torus(size_t)> &f) const {  // :146-153
     return assemble(f);
+  }
+  void generate_lookup_table_full_assign(const std::function<Torus(size_t)> &f, LookupTable &lut_out) const {  // :160-203
+    lut_out = assemble(f);
+  }
+  LookupTable generate_lookup_table_custom(const std::function<size_t(size_t)> &f, size_t message_modulus, double scale) const {  // :205-222
+    return Generator(message_modulus, scale).generate_lookup_table(f);
+  }
+  size_t mod_switch(Torus x) const {  // :235-238: (x / u32::MAX * size).round() % size
+    const double scaled = (double)x / 4294967295.0 * (double)N;
+    return (size_t)std::floor(scaled + 0.5) % (size_t)N;
   }
 
  private:

@@ -99,9 +99,15 @@ class Generator:
         m = self.message_modulus
         return self._assemble([self.encoder.encode(f(x)) for x in range(m)])
 
+    def generate_lookup_table_assign(self, f, lut_out: LookupTable) -> None:  # generator.rs:89-137: into an existing table
+        lut_out.copy_from(self.generate_lookup_table(f))
+
     def generate_lookup_table_full(self, f) -> LookupTable:  # generator.rs:146-153
         m = self.message_modulus
         return self._assemble([int(f(x)) & 0xFFFFFFFF for x in range(m)])
+
+    def generate_lookup_table_full_assign(self, f, lut_out: LookupTable) -> None:  # generator.rs:160-203
+        lut_out.copy_from(self.generate_lookup_table_full(f))
 
     def generate_lookup_table_custom(self, f, message_modulus: int, scale: float) -> LookupTable:  # :203-222
         return Generator(message_modulus, scale).generate_lookup_table(f)

@@ -211,6 +211,21 @@ int main() {
       LutBootstrap lb;
       Ciphertext r = lb.bootstrap_lut(x + y, gen.generate_lookup_table([](size_t v) { return (v + 1) % 4; }), gk);
       CHECK(tlwe::decrypt_lwe_message(r, 4, sk.key_lv0) == 0, "bootstrap_lut(x + y)");
+      // the rest of the generator / lookup-table surface (generator.rs:89-137, 160-222, 235-238; lookup_table.rs:33-68)
+      lut::LookupTable t1 = gen.generate_lookup_table([](size_t v) { return (3 * v + 1) % 4; }), t2;
+      CHECK(t2.is_empty() && !t1.is_empty(), "LookupTable::is_empty");
+      gen.generate_lookup_table_assign([](size_t v) { return (3 * v + 1) % 4; }, t2);
+      CHECK(t2.poly.b == t1.poly.b && t2.poly.a == t1.poly.a, "generate_lookup_table_assign");
+      lut::LookupTable t3 = gen.generate_lookup_table_full([&](size_t v) { return lut::Encoder(4).encode((3 * v + 1) % 4); });
+      CHECK(t3.poly.b == t1.poly.b, "generate_lookup_table_full with the encoder's values = generate_lookup_table");
+      gen.generate_lookup_table_full_assign([&](size_t v) { return lut::Encoder(4).encode((3 * v + 1) % 4); }, t2);
+      CHECK(t2.poly.b == t1.poly.b, "generate_lookup_table_full_assign");
+      CHECK(lut::Generator(2).generate_lookup_table_custom([](size_t v) { return (3 * v + 1) % 4; }, 4, 1.0 / 8.0).poly.b == t1.poly.b, "generate_lookup_table_custom");
+      CHECK(lut::LookupTable::from_poly(t1.poly).poly.b == t1.poly.b, "LookupTable::from_poly");
+      t2.clear();
+      CHECK(t2.is_empty(), "LookupTable::clear");
+      CHECK(gen.mod_switch(0) == 0 && gen.mod_switch(0x80000000u) == 512 && gen.mod_switch(0xFFFFFFFFu) == 0 && gen.mod_switch(0x00200000u) == 1,
+            "mod_switch (generator.rs:235-238)");
     }
     // proxy re-encryption through the header alone (src/proxy_reenc.rs): Alice -> Bob symmetric, and through Bob's
     // public key; the GPU's words equal reencrypt_tlwe_lv0 (:468-510) of the oracle on the same key

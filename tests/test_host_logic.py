@@ -179,6 +179,17 @@ def test_lut_generator_matches_oracle(O):
     full = g.generate_lookup_table_full(lambda x: Encoder(4).encode(x))
     assert np.array_equal(full.poly, g.generate_lookup_table(lambda x: x).poly)
     assert not Generator(2).generate_lookup_table(lambda x: x).is_empty()  # generator.rs:281-333
+    # the _assign forms write into an existing table (generator.rs:89-137, 160-203)
+    from rs_tfhe_amd.lut import LookupTable
+
+    t1, t2 = g.generate_lookup_table(lambda x: (3 * x + 1) % 4), LookupTable()
+    assert t2.is_empty()
+    g.generate_lookup_table_assign(lambda x: (3 * x + 1) % 4, t2)
+    assert np.array_equal(t2.poly, t1.poly)
+    t2.clear()
+    g.generate_lookup_table_full_assign(lambda x: Encoder(4).encode((3 * x + 1) % 4), t2)
+    assert np.array_equal(t2.poly, t1.poly)
+    assert g.mod_switch(0) == 0 and g.mod_switch(0x80000000) == 512 and g.mod_switch(0xFFFFFFFF) == 0 and g.mod_switch(0x00200000) == 1
 
 
 def test_shard_range_partitions():
