@@ -758,9 +758,19 @@ inline Ciphertext and_(const Ciphertext &a, const Ciphertext &b, const CloudKey 
 inline Ciphertext xor_(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().xor_(a, b, k); }
 inline Ciphertext xnor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().xnor(a, b, k); }
 inline Ciphertext nor(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().nor(a, b, k); }
+inline Ciphertext and_ny(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().and_ny(a, b, k); }
+inline Ciphertext and_yn(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().and_yn(a, b, k); }
+inline Ciphertext or_ny(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().or_ny(a, b, k); }
+inline Ciphertext or_yn(const Ciphertext &a, const Ciphertext &b, const CloudKey &k) { return Gates().or_yn(a, b, k); }
+inline Ciphertext mux(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) {
+  return Gates().mux(a, b, c, k);
+}
 inline Ciphertext mux_naive(const Ciphertext &a, const Ciphertext &b, const Ciphertext &c, const CloudKey &k) {
   return Gates().mux_naive(a, b, c, k);
 }
+inline Ciphertext not_(const Ciphertext &a) { return Gates().not_(a); }                    // gates.rs:314-316
+inline Ciphertext copy(const Ciphertext &a) { return Gates().copy(a); }                    // gates.rs:319-321
+inline Ciphertext constant(bool value, int n) { return Gates().constant(value, n); }       // gates.rs:324-326
 using Pairs = std::vector<std::pair<Ciphertext, Ciphertext>>;
 inline std::vector<Ciphertext> batch_nand(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_NAND, in, k); }
 inline std::vector<Ciphertext> batch_and(const Pairs &in, const CloudKey &k) { return detail::batch_gate(TFHE_HIP_AND, in, k); }

@@ -117,6 +117,9 @@ def or_ny(a, b, cloud_key): return Gates().or_ny(a, b, cloud_key)
 def or_yn(a, b, cloud_key): return Gates().or_yn(a, b, cloud_key)
 def mux(a, b, c, cloud_key): return Gates().mux(a, b, c, cloud_key)
 def mux_naive(a, b, c, cloud_key): return Gates().mux_naive(a, b, c, cloud_key)
+def not_(a): return Gates().not_(a)  # gates.rs:314-316
+def copy(a): return Gates().copy(a)  # gates.rs:319-321
+def constant(value: bool, n: int): return Gates().constant(value, n)  # gates.rs:324-326 (n: the ciphertexts' dimension)
 
 
 # batch free functions (src/gates.rs:352-547); inputs_a/inputs_b: [count][n+1]
