@@ -36,9 +36,18 @@
  * context is safe but serialising; use one context per stream for overlap.
  *
  * Thread safety: a context may be used from several host threads (the
- * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23); calls on one
- * context are serialised internally, first come first served (a thread that
- * issues calls back to back cannot starve the others).
+ * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23).  Concurrent SMALL
+ * host-pointer calls (tfhe_hip_batch_gate / _gates_mixed[_nks] / _bootstrap / _mux
+ * of up to #CUs ciphertexts, and their tfhe_hip_pool_* forms) are MERGED: whatever
+ * calls arrive while a launch is running share the next one (one launch per key
+ * view and operation class, per-ciphertext gate codes / test vectors), so T threads
+ * that each evaluate one gate get T gates per launch time, not one -- what a Rayon
+ * team calling one strategy expects of its cores (src/parallel/rayon_impl.rs:40-47).
+ * Results are the same bits as the unmerged call; a lone caller sees the latency of
+ * a one-ciphertext call; errors stay with the thread that caused them.  See
+ * tfhe_hip_set_combining.  Every other call on one context is serialised
+ * internally, first come first served (a thread that issues calls back to back
+ * cannot starve the others).
  */
 #ifndef TFHE_HIP_H
 #define TFHE_HIP_H
@@ -332,6 +341,28 @@ int tfhe_hip_batch_ifft(tfhe_hip_ctx *ctx, double *res, const uint32_t *src, siz
 int tfhe_hip_batch_fft(tfhe_hip_ctx *ctx, uint32_t *res, const double *src, size_t count);
 int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
                             const uint32_t *b, size_t count);
+
+/* ---- concurrent callers --------------------------------------------------- */
+
+/* Replaces: the concurrency a `Send + Sync` strategy gets from Rayon's workers (src/bootstrap/mod.rs:23-38,
+ * src/parallel/rayon_impl.rs:40-47).  Host-pointer calls of at most `max_count` ciphertexts are merged with the calls
+ * other threads make meanwhile (see "Thread safety" above); larger calls run alone, as before.  The default bound is
+ * the device's CU count (one GPU runs that many ciphertexts in the time of one); 0 switches merging off, the largest
+ * bound is 4096.  The environment variable TFHE_HIP_COMBINE (a number, 0 = off), read when a context is created,
+ * sets the same bound.  Accepts a context or a key view (the setting is the context's). */
+int tfhe_hip_set_combining(tfhe_hip_ctx *ctx, size_t max_count);
+
+typedef struct tfhe_hip_combine_stats {
+  uint64_t max_count;               /* the bound in force                                         */
+  uint64_t launches;                /* merged launches issued                                     */
+  uint64_t requests;                /* calls they carried                                         */
+  uint64_t ciphertexts;             /* ciphertexts they carried                                   */
+  uint64_t max_requests_per_launch; /* most calls taken by one leader at once                     */
+  uint64_t lingers;                 /* leaders that waited for the previous launch's callers      */
+  double linger_us;                 /* ... and for how long in all                                */
+} tfhe_hip_combine_stats;
+/* Counters since the last call; resets them. */
+int tfhe_hip_get_combine_stats(tfhe_hip_ctx *ctx, tfhe_hip_combine_stats *out);
 
 /* ---- measurement -------------------------------------------------------- */
 

@@ -53,6 +53,14 @@ class PoolTransferTimes(C.Structure):
                 ("calls", C.c_uint64), ("comm_create_ms", C.c_double), ("key_replication_ms", C.c_double)]
 
 
+class CombineStats(C.Structure):
+    """struct tfhe_hip_combine_stats"""
+
+    _fields_ = [("max_count", C.c_uint64), ("launches", C.c_uint64), ("requests", C.c_uint64),
+                ("ciphertexts", C.c_uint64), ("max_requests_per_launch", C.c_uint64), ("lingers", C.c_uint64),
+                ("linger_us", C.c_double)]
+
+
 _P = C.c_void_p
 _SZ = C.c_size_t
 _CTX = C.c_void_p
@@ -112,6 +120,8 @@ SIGNATURES = {
     "tfhe_hip_get_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_get_key_switch_clock_sample": (C.c_int, [_CTX, C.POINTER(ClockSample)]),
     "tfhe_hip_synchronize": (C.c_int, [_CTX]),
+    "tfhe_hip_set_combining": (C.c_int, [_CTX, _SZ]),
+    "tfhe_hip_get_combine_stats": (C.c_int, [_CTX, C.POINTER(CombineStats)]),
     "tfhe_hip_describe_dispatch": (C.c_int, [_CTX, _SZ, C.c_char_p, _SZ]),
     "tfhe_hip_rounding_mode": (C.c_char_p, [_CTX]),
     # several GPUs behind one handle

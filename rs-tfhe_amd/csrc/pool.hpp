@@ -54,6 +54,7 @@ struct tfhe_hip_pool {
   // byte-plane builds), so that neither hides inside a "key generation" figure
   double comm_create_ms = 0.0, key_replication_ms = 0.0;
 
+  ~tfhe_hip_pool() { handle_gone(id); }
   tfhe_hip_pool *root() { return parent ? parent : this; }
   const tfhe_hip_pool *root() const { return parent ? parent : this; }
 };
@@ -81,6 +82,7 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
+  comb_quiesce(ctx);
   const tfhe_hip_params &P = ctx->P;
   const size_t bsk_bytes = (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double);
   const size_t ksk_bytes = (size_t)kN * P.t * (1u << P.basebit) * ksk_row_words(P.n) * 4;
@@ -201,6 +203,7 @@ int prepare_replica(tfhe_hip_ctx *member) {
   if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
+  comb_quiesce(ctx);
   const tfhe_hip_params &P = ctx->P;
   ctx->K->key_loaded = ctx->K->reenc_loaded = false;
   if (!ctx->K->d_bsk) HIPCHK(ctx, hipMalloc((void **)&ctx->K->d_bsk, (size_t)P.n * 2 * P.l * 2 * kN * sizeof(double)));
@@ -669,7 +672,6 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
       for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);  // (drains the member's queued work first)
       last_of_dying = --root->views == 0 && root->dying;
     }
-    handle_gone(p->id);
     delete p;
     if (last_of_dying) tfhe_hip_pool_destroy(root);  // the parent was destroyed first: it has waited for its views
     return;
@@ -707,7 +709,6 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
     }
   if (prev >= 0) (void)hipSetDevice(prev);
   for (auto *c : p->ctxs) tfhe_hip_ctx_destroy(c);
-  handle_gone(p->id);
   delete p;
 }
 
@@ -763,6 +764,34 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 #define POOL_ENTER(p)               \
   if (!(p)) return TFHE_HIP_EINVAL; \
   std::lock_guard<FairMutex> plk_((p)->root()->own_mu)
+
+// Small host-pointer calls from concurrent threads (`Send + Sync`, src/bootstrap/mod.rs:23): they do not queue on the
+// pool's mutex; each goes to the member whose combining front end (combine.hpp) has the least work queued and in
+// flight, where it shares launches with the other threads' calls.  (Key loads and device-resident calls keep the
+// pool's mutex; as for a context, changing a key while calls under it are in flight is the caller's to avoid.)
+namespace {
+inline bool pool_small(const tfhe_hip_pool *p, size_t count) { return p && !p->ctxs.empty() && comb_takes(p->ctxs[0], count); }
+inline tfhe_hip_ctx *pool_least_loaded(tfhe_hip_pool *p) {
+  tfhe_hip_ctx *best = p->ctxs[0];
+  size_t best_load = ~(size_t)0;
+  for (tfhe_hip_ctx *c : p->ctxs) {
+    const tfhe_hip_ctx *base = c->parent ? c->parent : c;
+    const size_t load = base->comb ? base->comb->pending.load(std::memory_order_relaxed) : 0;
+    if (load < best_load) {
+      best = c;
+      best_load = load;
+    }
+  }
+  return best;
+}
+template <class F>
+int pool_small_call(tfhe_hip_pool *p, F &&call) {
+  tfhe_hip_ctx *c = pool_least_loaded(p);
+  const int rc = call(c);
+  if (rc != TFHE_HIP_OK) return pool_fail(p, rc, "device " + std::to_string(c->device) + ": " + tfhe_hip_last_error(c));
+  return TFHE_HIP_OK;
+}
+}  // namespace
 #define POOL_FIRST(p, call)                                                                                        \
   do {                                                                                                             \
     const int rc_ = (call);                                                                                        \
@@ -810,6 +839,10 @@ int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *p, int member, double *bsk, ui
 // ---- host-pointer batch calls: one host thread per shard ---------------------------------------------------------
 int tfhe_hip_pool_batch_gate(tfhe_hip_pool *p, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
                              size_t count) {
+  if (pool_small(p, count)) {
+    if (!a || !out) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_gate(c, gate, a, b, out, count); });
+  }
   POOL_ENTER(p);
   if (count && (!a || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;
@@ -820,6 +853,10 @@ int tfhe_hip_pool_batch_gate(tfhe_hip_pool *p, int gate, const uint32_t *a, cons
 
 int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *p, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                     uint32_t *out, size_t count) {
+  if (pool_small(p, count)) {
+    if (!gates || !a || !b || !out) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_gates_mixed(c, gates, a, b, out, count); });
+  }
   POOL_ENTER(p);
   if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;
@@ -830,6 +867,10 @@ int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *p, const uint8_t *gates, cons
 
 int tfhe_hip_pool_batch_gates_mixed_nks(tfhe_hip_pool *p, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                         uint32_t *out, size_t count) {
+  if (pool_small(p, count)) {
+    if (!gates || !a || !b || !out) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_gates_mixed_nks(c, gates, a, b, out, count); });
+  }
   POOL_ENTER(p);
   if (count && (!gates || !a || !b || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;
@@ -840,6 +881,10 @@ int tfhe_hip_pool_batch_gates_mixed_nks(tfhe_hip_pool *p, const uint8_t *gates, 
 
 int tfhe_hip_pool_batch_bootstrap(tfhe_hip_pool *p, const uint32_t *in, const uint32_t *testvec, int per_ct,
                                   int keyswitch, uint32_t *out, size_t count) {
+  if (pool_small(p, count)) {
+    if (!in || !out) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_bootstrap(c, in, testvec, per_ct, keyswitch, out, count); });
+  }
   POOL_ENTER(p);
   if (count && (!in || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;
@@ -875,6 +920,10 @@ int tfhe_hip_pool_batch_lincomb_bootstrap(tfhe_hip_pool *p, uint32_t ca, const u
 
 int tfhe_hip_pool_batch_mux(tfhe_hip_pool *p, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c3,
                             uint32_t *out, size_t count) {
+  if (pool_small(p, count)) {
+    if (!a || !b || !c3 || !out) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_mux(c, naive, a, b, c3, out, count); });
+  }
   POOL_ENTER(p);
   if (count && (!a || !b || !c3 || !out)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;

@@ -136,6 +136,8 @@ struct KeyState {
   bool reenc_loaded = false;  // d_ksk (+ d_ksk8) hold a proxy re-encryption key (proxy_reenc.rs:224-233) instead of a cloud key's
 };
 
+struct Combiner;  // combine.hpp: the combining front end of the small host-pointer calls
+
 struct tfhe_hip_ctx {
   tfhe_hip_params P{};
   int device = 0;
@@ -147,7 +149,10 @@ struct tfhe_hip_ctx {
   bool dying = false;            // destroyed while views were alive: the last view to go frees the context
   double2 *d_tw = nullptr;
   DevBuf lv1, u1, u2, h_a, h_b, h_c, h_out, h_tv, h_idx, ks_out, ks_dig;  // scratch / host-API staging (ks_dig: key-switch digit bytes)
-  PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members only)
+  PinBuf p_a, p_b, p_c, p_out;  // pinned staging arenas behind h_a / h_b / h_c / h_out (pool members, combiner lanes)
+  PinBuf p_tv, p_idx;           // ... behind h_tv / h_idx (combiner lanes only)
+  Combiner *comb = nullptr;      // base contexts: concurrent small host-pointer calls are merged into shared launches (combine.hpp)
+  bool is_lane = false;          // this context is a combiner lane of another one (never handed to a caller)
   bool stage_pinned = false;     // set by a pool with several members: stage pageable operands through the arenas
   FairMutex mu;  // one call at a time per context, first come first served
   uint64_t id = new_handle_id();  // key of this context's per-thread error text (err_slot)
@@ -180,6 +185,7 @@ struct tfhe_hip_ctx {
   // sums for the matrix-core key switch
   unsigned long long *d_diag = nullptr;
   int rtc_khz = 100000;  // rate of s_memrealtime (hipDeviceAttributeWallClockRate)
+  ~tfhe_hip_ctx() { handle_gone(id); }  // (registration and erasure cannot drift apart: every `delete` passes here)
 };
 
 namespace {
@@ -983,6 +989,8 @@ T *pinned_view(T *p, size_t bytes) {
 
 }  // namespace
 
+#include "combine.hpp"
+
 // =============================================================================
 // C ABI
 // =============================================================================
@@ -1048,6 +1056,16 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     }
     ks_force = k + 1;
   }
+  long combine_env = -1;  // -1: the default (the device's CU count)
+  if (const char *env = getenv("TFHE_HIP_COMBINE")) {
+    char *end = nullptr;
+    const long v = strtol(env, &end, 10);
+    if (*env && end && *end == 0 && v >= 0 && v <= (long)Combiner::kBatchCap) combine_env = v;
+    else if (*env) {
+      g_create_error = "TFHE_HIP_COMBINE must be 0 (off) or the largest call to merge, at most 4096 ciphertexts";
+      return TFHE_HIP_EINVAL;
+    }
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1077,6 +1095,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
   ctx->num_cus = prop.multiProcessorCount;
+  const size_t combine_max = combine_env >= 0 ? (size_t)combine_env : (size_t)ctx->num_cus;
   // pre-rounding magnitude bound: 2l polynomials x N terms x (Bg/2) digit x 2^31 key coefficient
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   // crossovers of the automatic dispatch, measured on the 256-CU part and kept as multiples of the CU count:
@@ -1157,8 +1176,12 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
     return bail("hipMalloc twiddles", e);
   if ((e = hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
     return bail("hipMemcpy twiddles", e);
-  // the persistent kernel may want > 64 KiB of dynamic LDS only for absurd n; the
-  // default limit (64 KiB) is ample: 9216 + 2n bytes.
+  // The combining front end (combine.hpp): host-pointer calls of up to `max_count` ciphertexts from concurrent threads
+  // share launches.  One device runs up to #CUs ciphertexts in the time of one (every ciphertext its own workgroup), so
+  // that is the default bound; TFHE_HIP_COMBINE=0 switches the front end off, any other number is the bound
+  // (tfhe_hip_set_combining changes it at run time).
+  ctx->comb = new Combiner();
+  ctx->comb->max_count = combine_max;
   *out = ctx;
   return TFHE_HIP_OK;
 }
@@ -1183,10 +1206,10 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
       DeviceGuard dg(base->device);
       if (base->scratch_owned && base->scratch_owner != base->stream) (void)hipStreamSynchronize(base->scratch_owner);
       if (base->stream) (void)hipStreamSynchronize(base->stream);
+      comb_quiesce(base);  // (merged launches run on the lanes' streams)
       free_key(ctx->own);
       last_of_dying = --base->views == 0 && base->dying;
-      handle_gone(ctx->id);  // (a view's id keys no text -- its errors are its parent's -- but it is registered as live)
-      delete ctx;
+      delete ctx;  // (a view's id keys no text -- its errors are its parent's -- but it is registered as live until here)
     }
     if (last_of_dying) tfhe_hip_ctx_destroy(base);  // the parent was destroyed first: it has waited for its views
     return;
@@ -1201,6 +1224,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     }
   }
   DeviceGuard dg(ctx->device);
+  comb_destroy(ctx);  // the front end's lanes (private sibling contexts) go first
   if (ctx->scratch_owned && ctx->scratch_owner != ctx->stream) (void)hipStreamSynchronize(ctx->scratch_owner);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->d_diag) (void)hipFree(ctx->d_diag);
@@ -1216,11 +1240,10 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
   for (DevBuf *b : bufs)
     if (b->p) (void)hipFree(b->p);
   free_key(ctx->own);
-  for (PinBuf *b : {&ctx->p_a, &ctx->p_b, &ctx->p_c, &ctx->p_out})
+  for (PinBuf *b : {&ctx->p_a, &ctx->p_b, &ctx->p_c, &ctx->p_out, &ctx->p_tv, &ctx->p_idx})
     if (b->p) (void)hipHostFree(b->p);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-  handle_gone(ctx->id);
   delete ctx;
 }
 
@@ -1259,6 +1282,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
+  comb_quiesce(ctx);  // ... and merged launches on the front end's lanes
   const tfhe_hip_params &P = ctx->P;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
   const size_t bsk_bytes = polys * kN * sizeof(double);
@@ -1313,6 +1337,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
+  comb_quiesce(ctx);  // ... and merged launches on the front end's lanes
   const tfhe_hip_params &P = ctx->P;
   const int base = 1 << P.basebit;
   const size_t polys = (size_t)P.n * 2 * P.l * 2;
@@ -1481,6 +1506,7 @@ int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
   if (!ctx->K->d_bsk || !ctx->K->d_ksk || !ctx->K->d_testvec)
     return fail(ctx, TFHE_HIP_EINVAL, "tfhe_hip_adopt_cloud_key before tfhe_hip_cloud_key_buffers");
   // whatever filled the buffers (a peer copy, an RCCL broadcast on another stream) must have finished
+  comb_quiesce(ctx);
   HIPCHK(ctx, hipDeviceSynchronize());
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = decomp_offset;
@@ -1572,9 +1598,67 @@ int tfhe_hip_batch_mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, cons
 
 // ---- host-pointer entry points -----------------------------------------------
 
+// Small calls (comb_takes) go through the combining front end: the caller checks its own arguments, exactly as the
+// direct path below does and in the same order, then queues (combine.hpp).
+namespace {
+#define COMB_FAIL(base, code, msg)      \
+  do {                                  \
+    err_slot((base)->id) = (msg);       \
+    return (code);                      \
+  } while (0)
+int comb_gate_call(tfhe_hip_ctx *ctx, int gate, const uint8_t *codes, int keyswitch, const uint32_t *a, const uint32_t *b,
+                   const uint32_t *testvec, int per_ct, uint32_t *out, size_t count) {
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  if (!ctx->own.key_loaded) COMB_FAIL(base, TFHE_HIP_ENOKEY, "cloud key not loaded");
+  if (codes) {
+    if (!a || !b || !out) COMB_FAIL(base, TFHE_HIP_EINVAL, "null pointer");
+    for (size_t i = 0; i < count; ++i)
+      if (codes[i] > TFHE_HIP_COPY) COMB_FAIL(base, TFHE_HIP_EINVAL, "unknown gate");
+  } else {
+    GatePrep gp;
+    if (!gate_prep(gate, gp)) COMB_FAIL(base, TFHE_HIP_EINVAL, "unknown gate");
+    if (!a || !out || (gp.cb && !b)) COMB_FAIL(base, TFHE_HIP_EINVAL, "null pointer");
+  }
+  if (!keyswitch && base->P.n > kN)
+    COMB_FAIL(base, TFHE_HIP_EINVAL, "bootstrap without key switch needs n <= N (sample_extract_index_2)");
+  CombReq r;
+  r.key = &ctx->own;
+  r.cls = CB_GATES;
+  r.gate = gate;
+  r.codes = codes;
+  r.keyswitch = keyswitch;
+  r.a = a;
+  r.b = b;
+  r.testvec = testvec;
+  r.per_ct = per_ct;
+  r.out = out;
+  r.count = count;
+  return comb_submit(base, r);
+}
+int comb_mux_call(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out,
+                  size_t count) {
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  if (!ctx->own.key_loaded) COMB_FAIL(base, TFHE_HIP_ENOKEY, "cloud key not loaded");
+  if (!a || !b || !c || !out) COMB_FAIL(base, TFHE_HIP_EINVAL, "null pointer");
+  if (!naive && base->P.n > kN)
+    COMB_FAIL(base, TFHE_HIP_EINVAL, "bootstrap without key switch needs n <= N (sample_extract_index_2)");
+  CombReq r;
+  r.key = &ctx->own;
+  r.cls = naive ? CB_MUX_NAIVE : CB_MUX;
+  r.a = a;
+  r.b = b;
+  r.c = c;
+  r.out = out;
+  r.count = count;
+  return comb_submit(base, r);
+}
+#undef COMB_FAIL
+}  // namespace
+
 int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const uint32_t *b,
                         uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count)) return comb_gate_call(ctx, gate, nullptr, 1, a, b, nullptr, 0, out, count);
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
@@ -1601,6 +1685,7 @@ int tfhe_hip_batch_gate(tfhe_hip_ctx *ctx, int gate, const uint32_t *a, const ui
 int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count) && gates) return comb_gate_call(ctx, 0, gates, 1, a, b, nullptr, 0, out, count);
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
@@ -1629,6 +1714,7 @@ int tfhe_hip_batch_gates_mixed(tfhe_hip_ctx *ctx, const uint8_t *gates, const ui
 int tfhe_hip_batch_gates_mixed_nks(tfhe_hip_ctx *ctx, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
                                    uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count) && gates) return comb_gate_call(ctx, 0, gates, 0, a, b, nullptr, 0, out, count);
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
@@ -1648,6 +1734,8 @@ int tfhe_hip_batch_gates_mixed_nks(tfhe_hip_ctx *ctx, const uint8_t *gates, cons
 int tfhe_hip_batch_bootstrap(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                              int per_ct, int keyswitch, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count))
+    return comb_gate_call(ctx, TFHE_HIP_COPY, nullptr, keyswitch != 0, in, nullptr, testvec, per_ct, out, count);
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
@@ -1739,6 +1827,7 @@ int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uin
 int tfhe_hip_batch_mux(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b,
                        const uint32_t *c, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count)) return comb_mux_call(ctx, naive, a, b, c, out, count);
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;
@@ -1830,6 +1919,7 @@ int tfhe_hip_load_reenc_key(tfhe_hip_ctx *ctx, const uint32_t *key) {
   if (ctx->scratch_owned) HIPCHK(ctx, hipStreamSynchronize(ctx->scratch_owner));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->scratch_owned = false;
+  comb_quiesce(ctx);  // ... and merged launches on the front end's lanes
   const int base = 1 << P.basebit;
   const size_t eng_bytes = (size_t)kN * P.t * base * ksk_row_words(P.n) * 4;
   const size_t rows = (size_t)P.n * P.t * base, words = rows * (size_t)(P.n + 1);
@@ -1931,6 +2021,11 @@ int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled) {
     HIPCHK(ctx, hipMemsetAsync(ctx->d_diag + 4, 0, 16, ctx->stream));
   }
   ctx->profiling = enabled != 0;
+  comb_with_idle_lanes(ctx, [&](Combiner &C) {  // the front end's lanes record their launches too
+    C.profiling = enabled != 0;
+    for (auto &L : C.lane)
+      if (L.x) L.x->profiling = enabled != 0;
+  });
   return TFHE_HIP_OK;
 }
 
@@ -1955,7 +2050,17 @@ int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out) {
   CHK(drain(ctx->ev_ks, out->key_switch_ms, out->key_switch_launches));
   out->bootstraps = ctx->bootstraps;
   ctx->bootstraps = 0;
-  return TFHE_HIP_OK;
+  int lane_rc = TFHE_HIP_OK;  // merged launches of small calls ran on the front end's lanes
+  comb_with_idle_lanes(ctx, [&](Combiner &C) {
+    for (auto &L : C.lane) {
+      if (!L.x) continue;
+      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(L.x->ev_br, out->blind_rotate_ms, out->blind_rotate_launches);
+      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(L.x->ev_ks, out->key_switch_ms, out->key_switch_launches);
+      out->bootstraps += L.x->bootstraps;
+      L.x->bootstraps = 0;
+    }
+  });
+  return lane_rc;
 }
 
 int tfhe_hip_get_clock_sample(tfhe_hip_ctx *ctx, tfhe_hip_clock_sample *out) {
@@ -2028,6 +2133,36 @@ extern "C" int tfhe_hip_experiment_diag(tfhe_hip_ctx *ctx, unsigned long long *o
   return TFHE_HIP_OK;
 }
 #endif
+
+int tfhe_hip_set_combining(tfhe_hip_ctx *ctx, size_t max_count) {
+  if (!ctx) return TFHE_HIP_EINVAL;
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  if (max_count > Combiner::kBatchCap) {
+    err_slot(base->id) = "tfhe_hip_set_combining: at most 4096 ciphertexts per merged call";
+    return TFHE_HIP_EINVAL;
+  }
+  if (base->comb) base->comb->max_count.store(max_count, std::memory_order_relaxed);
+  return TFHE_HIP_OK;
+}
+
+int tfhe_hip_get_combine_stats(tfhe_hip_ctx *ctx, tfhe_hip_combine_stats *out) {
+  if (!ctx || !out) return TFHE_HIP_EINVAL;
+  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+  memset(out, 0, sizeof(*out));
+  Combiner *C = base->comb;
+  if (!C) return TFHE_HIP_OK;
+  std::lock_guard<std::mutex> lk(C->mu);
+  out->max_count = C->max_count.load(std::memory_order_relaxed);
+  out->launches = C->st_launches;
+  out->requests = C->st_requests;
+  out->ciphertexts = C->st_cts;
+  out->max_requests_per_launch = C->st_max_requests;
+  out->lingers = C->st_lingers;
+  out->linger_us = C->st_linger_us;
+  C->st_launches = C->st_requests = C->st_cts = C->st_max_requests = C->st_lingers = 0;
+  C->st_linger_us = 0;
+  return TFHE_HIP_OK;
+}
 
 int tfhe_hip_host_alloc(size_t bytes, void **out) {
   if (!out) return TFHE_HIP_EINVAL;

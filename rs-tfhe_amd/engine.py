@@ -534,6 +534,18 @@ class Engine:
     def synchronize(self) -> None:
         self._chk(self._lib.tfhe_hip_synchronize(self._ctx))
 
+    # -- concurrent callers -------------------------------------------------------
+    def set_combining(self, max_count: int) -> None:
+        """Host-pointer calls of at most `max_count` ciphertexts made by concurrent threads share launches
+        (`tfhe_hip_set_combining`; the default is the device's CU count, 0 switches it off)."""
+        self._chk(self._lib.tfhe_hip_set_combining(self._ctx, int(max_count)))
+
+    def combine_stats(self) -> dict:
+        """Counters of the combining front end since the last call (`tfhe_hip_get_combine_stats`)."""
+        st = _capi.CombineStats()
+        self._chk(self._lib.tfhe_hip_get_combine_stats(self._ctx, C.byref(st)))
+        return {k: (float(getattr(st, k)) if k == "linger_us" else int(getattr(st, k))) for k, _ in st._fields_}
+
     @property
     def rounding_mode(self) -> str:
         """"fast" / "general": the blind-rotation kernels' rounding of the external product (`tfhe_hip_rounding_mode`)."""
@@ -602,6 +614,15 @@ class Pool:
 
     def __len__(self) -> int:
         return int(self._lib.tfhe_hip_pool_size(self._h))
+
+    def set_combining(self, max_count: int) -> None:
+        """`Engine.set_combining` on every member (small concurrent calls go to the least loaded member's front end)."""
+        for i in range(len(self)):
+            Engine.from_pool(self, i).set_combining(max_count)
+
+    def combine_stats(self) -> list:
+        """`Engine.combine_stats` of every member."""
+        return [Engine.from_pool(self, i).combine_stats() for i in range(len(self))]
 
     def _chk(self, rc: int) -> None:
         if rc != _capi.OK:

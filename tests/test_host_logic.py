@@ -75,17 +75,20 @@ def test_kernel_selectors_are_validated_without_gpu(monkeypatch):
     for var, val, params, text in (("TFHE_HIP_KS_KERNEL", "nonsense", good, b"TFHE_HIP_KS_KERNEL must be"),
                                    ("TFHE_HIP_BR_KERNEL", "wide", good, b"TFHE_HIP_BR_KERNEL must be"),
                                    ("TFHE_HIP_KS_KERNEL", "mfma", uint4, b"not available"),
-                                   ("TFHE_HIP_KS_KERNEL", "sliced", good, b"not available")):
+                                   ("TFHE_HIP_KS_KERNEL", "sliced", good, b"not available"),
+                                   ("TFHE_HIP_COMBINE", "many", good, b"TFHE_HIP_COMBINE must be"),
+                                   ("TFHE_HIP_COMBINE", "5000", good, b"TFHE_HIP_COMBINE must be")):
         monkeypatch.setenv(var, val)
         assert lib.tfhe_hip_ctx_create(ctypes.byref(params), 0, ctypes.byref(ctx)) == _capi.EINVAL, (var, val)
         assert text in lib.tfhe_hip_last_error(None), lib.tfhe_hip_last_error(None)
         monkeypatch.delenv(var)
     # the product library reads exactly the variables the header lists
-    src = "".join(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", f)).read() for f in ("tfhe_hip.hip", "pool.hpp"))
+    src = "".join(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", f)).read() for f in ("tfhe_hip.hip", "pool.hpp", "combine.hpp"))
     product = re.sub(r"#ifdef TFHE_EXPERIMENT.*?\n#endif\n#endif\n", "", src, flags=re.S)  # the experiment-only overrides
     read = set(re.findall(r'getenv\("(TFHE_HIP_[A-Z0-9_]+)"\)', product))
     hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
-    assert read == {"TFHE_HIP_BR_KERNEL", "TFHE_HIP_KS_KERNEL", "TFHE_HIP_POOL_RCCL", "TFHE_HIP_POOL_PINNED_STAGING"}, read
+    assert read == {"TFHE_HIP_BR_KERNEL", "TFHE_HIP_KS_KERNEL", "TFHE_HIP_POOL_RCCL", "TFHE_HIP_POOL_PINNED_STAGING",
+                    "TFHE_HIP_COMBINE"}, read
     for v in read:
         assert v in hdr
 
