@@ -346,6 +346,39 @@ def single_gate_latency(eng, gate, ca, cb, schedule=((0.0, 60), (0.010, 50), (1.
     return out
 
 
+def concurrent_single_gates(target, gate, ca, cb, threads=(1, 8, 64, 256), seconds=0.5):
+    """The reference's strategies are `Send + Sync` (src/bootstrap/mod.rs:23): T host threads (C++,
+    rs-tfhe_amd/csrc/callers.cpp -- a Rayon team's stand-in) each make one-ciphertext `Gates::nand`-shaped calls on ONE
+    handle, back to back.  The library merges the calls in flight into shared launches (combine.hpp); the aggregate
+    rate per team size, and the same calls with merging switched off (every call alone on the GPU, one after the
+    other) for comparison."""
+    import numpy as np
+
+    from rs_tfhe_amd import callers
+
+    rows, rates, med = len(ca), [], []
+    for T in threads:
+        est = 2.4e-3 * max(1.0, T / 256.0)
+        K = max(3, min(rows // T, int(seconds / est)))
+        n = T * K
+        codes = np.full(n, gate, np.uint8)
+        w = T * min(K, 2)
+        callers.run(target, callers.OP_GATE, ca[:w], cb[:w], gates=codes[:w], threads=T, calls=min(K, 2))  # lanes, arenas, threads
+        _, secs, ms = callers.run(target, callers.OP_GATE, ca[:n], cb[:n], gates=codes, threads=T, calls=K)
+        rates.append(round(n / secs, 1))
+        med.append(round(float(np.median(ms)), 3))
+    bound = target.combine_stats()["max_count"]
+    target.set_combining(0)
+    try:
+        T, K = 8, 12
+        _, secs, _ = callers.run(target, callers.OP_GATE, ca[:T * K], cb[:T * K], gates=np.full(T * K, gate, np.uint8), threads=T, calls=K)
+    finally:
+        target.set_combining(bound)
+    return {"threads": list(threads), "gates_per_s": rates, "call_ms_median": med,
+            "unmerged_gates_per_s_8_threads": round(T * K / secs, 1),
+            "what": "T host threads, one-ciphertext hom_nand calls with host buffers on one context, back to back"}
+
+
 def free_port() -> int:
     """A TCP port on 127.0.0.1 that is free now (bind to 0, read it back, release)."""
     import socket
@@ -723,21 +756,25 @@ def main():
             e["parallel_efficiency"] = round(e["bootstraps_per_s"] / (rate1 * e["threads"]), 3) if rate1 else None
         threads, sample, cpu_s = best[1], best[2], best[3]
         # BASELINE configs[0]: one hom_nand gate on one core (criterion gate_nand, benches/gate_benchmarks.rs:12-20)
-        t1 = time.perf_counter()
-        for r_ in range(3):
+        singles = []
+        for r_ in range(9):  # median of nine: the first calls after the sweep run on cold caches and a parked core
+            t1 = time.perf_counter()
             O.batch_gate(ock, gate, ca[r_:r_ + 1], cb[r_:r_ + 1], nthreads=1)
-        single_ms = (time.perf_counter() - t1) / 3 * 1e3
+            singles.append((time.perf_counter() - t1) * 1e3)
+        single_ms = sorted(singles)[len(singles) // 2]
         O.batch_gate(ock, gate, ca[:1], cb[:1], nthreads=allt)  # restore the OpenMP team size
         # the same single gate through the GPU path (host buffers, includes PCIe + sync), back to back and after idle
         # gaps (single_gate_latency): `gpu_single_gate_ms_warm` = median of back-to-back calls, `..._after_idle` =
         # median of calls that each follow 1 s of idle; the whole table is in `gpu_single_gate_latency`
         lat = single_gate_latency(eng, gate, ca, cb)
+        conc = concurrent_single_gates(eng, gate, ca, cb)
         cpu = {
             "value": round(best[0], 2),
             "single_gate_ms_1core": round(single_ms, 2),
             "gpu_single_gate_ms_warm": lat["0s"]["wall_ms_median"],
             "gpu_single_gate_ms_after_idle": lat["1s"]["wall_ms_median"],
             "gpu_single_gate_latency": lat,
+            "gpu_concurrent_single_gate": conc,
             "unit": "bootstraps/s",
             "cores": threads,
             "kind": "port",

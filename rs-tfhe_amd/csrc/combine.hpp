@@ -46,7 +46,8 @@ struct CombReq {
 };
 
 struct Combiner {
-  static constexpr int kLanes = 2;
+  static constexpr int kLanes = 4;  // most lanes a front end can have
+  int nlanes = 2;                   // lanes in use
   static constexpr size_t kBatchCap = 4096;  // ciphertexts per merged launch (bounds the pinned arenas)
   struct Lane {
     tfhe_hip_ctx *x = nullptr;  // created by its first leader
@@ -302,7 +303,7 @@ int comb_submit(tfhe_hip_ctx *base, CombReq &r) {
     while (!r.done) {
       int free_lane = -1;
       if (C.q.front() == &r)
-        for (int i = 0; i < Combiner::kLanes && free_lane < 0; ++i)
+        for (int i = 0; i < C.nlanes && free_lane < 0; ++i)
           if (!C.lane[i].busy) free_lane = i;
       if (free_lane >= 0) comb_lead(base, C, free_lane, lk);
       else C.cv.wait(lk);

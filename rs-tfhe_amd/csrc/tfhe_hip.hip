@@ -7,6 +7,7 @@
 // (src/gates.rs:357-383: prepare, batch_blind_rotate, extract + key switch).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1182,6 +1183,12 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   // (tfhe_hip_set_combining changes it at run time).
   ctx->comb = new Combiner();
   ctx->comb->max_count = combine_max;
+#ifdef TFHE_EXPERIMENT
+  if (const char *env = getenv("TFHE_HIP_COMBINE_LANES")) ctx->comb->nlanes = std::max(1, std::min((int)Combiner::kLanes, atoi(env)));
+  if (const char *env = getenv("TFHE_HIP_LINGER_WINDOW_US")) ctx->comb->linger_window_us = atol(env);
+  if (const char *env = getenv("TFHE_HIP_LINGER_QUIET_US")) ctx->comb->linger_quiet_us = atol(env);
+  if (const char *env = getenv("TFHE_HIP_LINGER_MAX_US")) ctx->comb->linger_max_us = atol(env);
+#endif
   *out = ctx;
   return TFHE_HIP_OK;
 }

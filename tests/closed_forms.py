@@ -1,0 +1,69 @@
+"""Closed forms that tie two integer stages to executed reference code / to arithmetic no restatement can share a slip
+with (used by tests/test_oracle_closed_forms.py on the CPU checker and tests/test_gpu_closed_forms.py on the HIP
+kernels).
+
+sample_extract_index (src/trlwe.rs:106-120).  For a TRLWE (a, b) under the ring key s, the sample extracted at index k
+must carry coefficient k of the phase polynomial b - a (*) s.  The reference "negates" with Torus::MAX - x (quirk Q1:
+-x - 1), so every wrapped position i > k contributes one extra s_i:
+    phase(extract_k) = (b - a (*) s)[k] + #{ i > k : s_i = 1 }                                   (mod 2^32)
+with a (*) s computed by the REFERENCE's own compiled Spqlios_poly_mul_1024 (oracle/_ref).  SPQLIOS truncates its
+output (fft_processor_spqlios.cpp:128-129: +-1 LSB), so `a` holds multiples of 256: a (*) s is then a multiple of 256 and
+rounding the reference product to the nearest one recovers it exactly.
+
+identity_key_switching (src/trgsw.rs:332-360) under a NOISE-FREE key-switching key (alpha = 0 in gen_key_switching_key,
+src/key.rs:102-122: row (i, j, k) encrypts k * s1_i / 2^((j+1) basebit) exactly):
+    phase(out) = src.b - sum_i s1_i * trunc_{t basebit}(a_i + PREC_OFFSET)                       (mod 2^32)
+where trunc keeps the top t * basebit bits and PREC_OFFSET = 2^(32 - (1 + basebit t)).  This sees what a decrypt test
+cannot: PREC_OFFSET, the digit order, the row index base*t*i + base*j + k and the sign.
+"""
+import ctypes as C
+
+import numpy as np
+
+N = 1024
+
+
+def round256(x):
+    return ((x.astype(np.uint64) + 128) // 256 * 256).astype(np.uint32)
+
+
+def extract_phase_expected(O, trlwe, key_lv1):
+    """[N] u32: for every k, what the phase of sample_extract_index(trlwe, k) must be (a = multiples of 256)."""
+    a, b = trlwe
+    assert not (a & 255).any()
+    prod = round256(O.ref_poly_mul(a, key_lv1.astype(np.uint32)))
+    phase_poly = (b - prod).astype(np.uint32)
+    s = key_lv1.astype(np.int64)
+    ones_above = (s.sum() - np.cumsum(s)).astype(np.uint32)  # [k] = #{i > k : s_i = 1}
+    return (phase_poly + ones_above).astype(np.uint32)
+
+
+def lv1_phase(lv1, key_lv1):
+    """b - <a, s1> of [count][N+1] level-1 samples"""
+    lv1 = np.asarray(lv1, np.uint32).reshape(-1, N + 1)
+    inner = (lv1[:, :N] * key_lv1.astype(np.uint32)[None, :]).sum(axis=1, dtype=np.uint32)
+    return (lv1[:, N] - inner).astype(np.uint32)
+
+
+def noise_free_ksk(O, params, sk, seed=99):
+    """orc_gen_key_switching_key (key.rs:102-122) with alpha = 0: [N][t][base][n+1]"""
+    import dataclasses
+
+    P0 = dataclasses.replace(params, alpha_lv0=0.0)
+    ksk = np.empty((N, params.t, params.base, params.n + 1), np.uint32)
+    cp = P0.c()
+    O.lib().orc_gen_key_switching_key(C.c_uint64(seed), C.byref(cp), sk.key_lv0.ctypes.data_as(C.c_void_p),
+                                      sk.key_lv1.ctypes.data_as(C.c_void_p), ksk.ctypes.data_as(C.c_void_p))
+    return ksk
+
+
+def key_switch_phase_expected(params, lv1, key_lv1, prec_offset=None):
+    """[count] u32: the phase the key-switched samples must have under key_lv0, for a noise-free key-switching key"""
+    lv1 = np.asarray(lv1, np.uint32).reshape(-1, N + 1)
+    bits = params.basebit * params.t
+    if prec_offset is None:
+        prec_offset = 1 << (32 - (1 + bits))
+    abar = (lv1[:, :N] + np.uint32(prec_offset)).astype(np.uint32)
+    trunc = abar & np.uint32((0xFFFFFFFF << (32 - bits)) & 0xFFFFFFFF)
+    inner = (trunc * key_lv1.astype(np.uint32)[None, :]).sum(axis=1, dtype=np.uint32)
+    return (lv1[:, N] - inner).astype(np.uint32)

@@ -23,6 +23,21 @@ void orc_gen_key_switching_key(uint64_t seed, const orc_params *P, const uint32_
 void orc_tlwe_encrypt_f64(uint64_t seed, double p, double alpha, const uint32_t *key, int dim, uint32_t *out);
 int orc_tlwe_decrypt_bool(const uint32_t *ct, const uint32_t *key, int dim);
 int orc_tlwe_decrypt_lwe_message(const uint32_t *ct, int m, const uint32_t *key, int dim);
+typedef struct {
+  orc_params P;
+  uint32_t decomposition_offset;
+  const uint32_t *testvec, *bsk_time_unused_;
+  const double *bsk_fft;
+} orc_cloud_key_head_;  // (layout check only; the real struct follows)
+typedef struct {
+  orc_params P;
+  uint32_t decomposition_offset;
+  const uint32_t *testvec;
+  const double *bsk_fft;
+  const uint32_t *bsk_time;
+  const uint32_t *ksk;
+} orc_cloud_key;
+int orc_batch_gate(const orc_cloud_key *ck, int op, const uint32_t *a, const uint32_t *b, uint32_t *out, int count, int nthreads);
 void orc_reencrypt_tlwe_lv0(const uint32_t *src, const uint32_t *key, const orc_params *P, uint32_t *out);
 // the four HIP runtime calls the device-resident pool test needs (libamdhip64 is linked; no HIP headers under g++)
 int hipMalloc(void **p, size_t bytes);
@@ -388,6 +403,63 @@ int main() {
       CHECK(bad.load() == 0, "per-thread error text: %d mismatches", bad.load());
     }
     lap("per-thread error text");
+    // ---- a team of threads calling ONE strategy (`Bootstrap: Send + Sync`, bootstrap/mod.rs:23; what
+    // `pairs.par_iter().map(|(a, b)| gates.nand(a, b, ck))` does with Rayon's workers): the library merges the calls
+    // that are in flight together into shared launches (combine.hpp).  Every result must be the CPU path's word for
+    // word, and the team must get many times what one thread gets.
+    {
+      const int T = 32, K = 12;
+      std::vector<Ciphertext> A, B, R((size_t)T * K, Ciphertext(P.n));
+      std::vector<int> op((size_t)T * K);
+      for (int i = 0; i < T * K; ++i) {
+        A.push_back(encrypt_bool((i * 7 + 1) % 3 == 0, P, key));
+        B.push_back(encrypt_bool((i * 5 + 2) % 4 < 2, P, key));
+        op[(size_t)i] = i % 3;  // nand, xor, and
+      }
+      Gates warm;
+      (void)warm.nand(A[0], B[0], cloud_key);  // the oracle-generated key is resident before the clock starts
+      auto one = [&](const Gates &g, int i) {
+        return op[(size_t)i] == 0 ? g.nand(A[(size_t)i], B[(size_t)i], cloud_key)
+               : op[(size_t)i] == 1 ? g.xor_(A[(size_t)i], B[(size_t)i], cloud_key)
+                                    : g.and_(A[(size_t)i], B[(size_t)i], cloud_key);
+      };
+      auto t0 = std::chrono::steady_clock::now();
+      {
+        Gates g;
+        for (int i = 0; i < 24; ++i) R[(size_t)i] = one(g, i);
+      }
+      const double alone = 24 / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      t0 = std::chrono::steady_clock::now();
+      std::vector<std::thread> team;
+      for (int t = 0; t < T; ++t)
+        team.emplace_back([&, t] {
+          Gates g;
+          for (int i = t * K; i < (t + 1) * K; ++i) R[(size_t)i] = one(g, i);
+        });
+      for (auto &th : team) th.join();
+      const double together = T * K / std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::printf("one thread %.0f gates/s, a team of %d threads %.0f gates/s\n", alone, T, together);
+      CHECK(together > 8 * alone, "a team of %d threads gets %.0f gates/s, one thread %.0f", T, together, alone);
+      orc_cloud_key ock{OP, cloud_key.decomposition_offset, cloud_key.blind_rotate_testvec.a.data(), cloud_key.bootstrapping_key.data(),
+                        nullptr, cloud_key.key_switching_key.data()};
+      const int codes[3] = {TFHE_HIP_NAND, TFHE_HIP_XOR, TFHE_HIP_AND};
+      int wrong = 0;
+      for (int c = 0; c < 3; ++c) {
+        std::vector<Torus> fa, fb;
+        std::vector<int> idx;
+        for (int i = c; i < T * K; i += 3) {
+          idx.push_back(i);
+          fa.insert(fa.end(), A[(size_t)i].p.begin(), A[(size_t)i].p.end());
+          fb.insert(fb.end(), B[(size_t)i].p.begin(), B[(size_t)i].p.end());
+        }
+        std::vector<Torus> fo(fa.size());
+        CHECK(orc_batch_gate(&ock, codes[c], fa.data(), fb.data(), fo.data(), (int)idx.size(), 0) == 0, "oracle gate");
+        for (size_t q = 0; q < idx.size(); ++q)
+          if (!std::equal(R[(size_t)idx[q]].p.begin(), R[(size_t)idx[q]].p.end(), fo.begin() + (long)(q * (size_t)(P.n + 1)))) ++wrong;
+      }
+      CHECK(wrong == 0, "team of threads: %d of %d results differ from the CPU path", wrong, T * K);
+    }
+    lap("a team of threads on one strategy");
     // OS-keyed generation (the default): a usable key, different every time
     {
       rs_tfhe::SecretKey sk3 = rs_tfhe::SecretKey::generate(P);

@@ -1,0 +1,62 @@
+"""The HIP kernels for sample_extract_index and identity_key_switching held to the closed forms of tests/closed_forms.py
+(the same identities tests/test_oracle_closed_forms.py holds the CPU checker to): the extraction against the REFERENCE's
+own compiled SPQLIOS product when oracle/_ref travels with the snapshot, the key switch against exact arithmetic under a
+noise-free key-switching key."""
+import numpy as np
+import pytest
+
+import closed_forms as CF
+from test_gpu_parity import _cloud_key, _product_params, eng128  # noqa: F401  (fixture)
+
+pytestmark = pytest.mark.gpu
+N = 1024
+
+
+def test_gpu_sample_extract_every_index_against_the_reference_product(O, eng128, keys128):
+    """k_sample_extract at EVERY k (trlwe.rs:106-120): phase of the extracted sample under key_lv1 == coefficient k of
+    b - a (*) s from the reference's Spqlios_poly_mul_1024 + #{i > k : s_i = 1} (quirk Q1)."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (it is built from /root/reference and travels as a binary)")
+    sk, _ = keys128
+    rng = np.random.default_rng(43)
+    a = (rng.integers(0, 2**24, (3, N), dtype=np.uint64) * 256).astype(np.uint32)
+    b = rng.integers(0, 2**32, (3, N), dtype=np.uint64).astype(np.uint32)
+    trlwe = np.stack([a, b], axis=1)  # [3][2][N]
+    exp = np.stack([CF.extract_phase_expected(O, t, sk.key_lv1) for t in trlwe])  # [3][N]
+    for k in range(N):
+        got = CF.lv1_phase(eng128.batch_sample_extract(trlwe, k), sk.key_lv1)
+        assert np.array_equal(got, exp[:, k]), k
+
+
+@pytest.mark.parametrize("setname,kernel", [
+    ("SECURITY_128_BIT", "auto"),     # base 4: split kernel at 5, matrix cores at 400
+    ("SECURITY_128_BIT", "b4"),
+    ("SECURITY_128_BIT", "generic"),
+    ("SECURITY_UINT4", "auto"),       # base 32: split at 5, column-sliced at 400
+    ("SECURITY_UINT4", "generic"),
+    ("SECURITY_UINT7", "auto"),       # base 128, n = 1160
+])
+def test_gpu_key_switch_exact_phase_under_a_noise_free_key(O, monkeypatch, setname, kernel):
+    """Every key-switch kernel family under a key-switching key generated with alpha = 0 (key.rs:102-122): the output's
+    phase under key_lv0 must equal src.b - sum_i s1_i * trunc_{t basebit}(a_i + PREC_OFFSET) EXACTLY -- PREC_OFFSET, digit
+    order, the row index base*t*i + base*j + k and the sign, none of which a decrypt test sees (trgsw.rs:332-360)."""
+    import rs_tfhe_amd as R
+
+    P = O.PARAM_SETS[setname]
+    sk = O.SecretKey(P, 78)
+    ksk = CF.noise_free_ksk(O, P, sk)
+    pp = _product_params(P)
+    pk = R.CloudKey(pp, np.zeros((P.n, 2 * P.l, 2, N)), ksk, 0, np.zeros((2, N), np.uint32))
+    monkeypatch.setenv("TFHE_HIP_KS_KERNEL", kernel)
+    eng = R.Engine(pp, 0)
+    eng.load_cloud_key(pk)
+    rng = np.random.default_rng(44)
+    bits = P.basebit * P.t
+    for count in (5, 400):
+        lv1 = rng.integers(0, 2**32, (count, N + 1), dtype=np.uint64).astype(np.uint32)
+        lv1[0, :N] = 0
+        lv1[-1, :N] = 0xFFFFFFFF
+        got = sk.phase(eng.batch_identity_key_switch(lv1))
+        assert np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1)), (setname, kernel, count, eng.describe_dispatch(count))
+        assert not np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1, prec_offset=1 << (32 - bits)))
+    eng.close()

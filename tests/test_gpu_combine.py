@@ -45,12 +45,13 @@ def test_sixty_four_threads_of_single_gates_share_launches(O, eng128, keys128):
     assert st["launches"] * 8 <= st["requests"] and st["max_requests_per_launch"] >= T // 2, st
     merged_rate = T * K / secs
     # the same calls one at a time: front end off, every call takes the context's mutex for its whole duration
+    bound = st["max_count"]
     eng128.set_combining(0)
     try:
         T1, K1 = 8, 12
         out1, secs1, _ = callers.run(eng128, callers.OP_GATE, ca[: T1 * K1], cb[: T1 * K1], gates=gates[: T1 * K1], threads=T1, calls=K1)
     finally:
-        eng128.set_combining(256)
+        eng128.set_combining(bound)
     k = np.arange(T1 * K1)
     assert np.array_equal(out1, out[k])  # merged or not: the same bits
     serial_rate = T1 * K1 / secs1

@@ -84,7 +84,8 @@ def test_kernel_selectors_are_validated_without_gpu(monkeypatch):
         monkeypatch.delenv(var)
     # the product library reads exactly the variables the header lists
     src = "".join(open(os.path.join(ROOT, "rs-tfhe_amd", "csrc", f)).read() for f in ("tfhe_hip.hip", "pool.hpp", "combine.hpp"))
-    product = re.sub(r"#ifdef TFHE_EXPERIMENT.*?\n#endif\n#endif\n", "", src, flags=re.S)  # the experiment-only overrides
+    product = re.sub(r"#ifdef TFHE_EXPERIMENT\n(?:(?!#if|#endif).)*#endif\n", "", src, flags=re.S)  # experiment-only overrides (a flat block)
+    product = re.sub(r"#ifdef TFHE_EXPERIMENT.*?\n#endif\n#endif\n", "", product, flags=re.S)  # ... (a block with one nested #ifdef)
     read = set(re.findall(r'getenv\("(TFHE_HIP_[A-Z0-9_]+)"\)', product))
     hdr = open(os.path.join(ROOT, "include", "tfhe_hip.h")).read()
     assert read == {"TFHE_HIP_BR_KERNEL", "TFHE_HIP_KS_KERNEL", "TFHE_HIP_POOL_RCCL", "TFHE_HIP_POOL_PINNED_STAGING",

@@ -1,0 +1,54 @@
+"""sample_extract_index and identity_key_switching of the CPU checker held to closed forms (tests/closed_forms.py):
+the first against the reference's own compiled SPQLIOS product, the second against exact arithmetic under a noise-free
+key-switching key.  CPU only."""
+import numpy as np
+import pytest
+
+import closed_forms as CF
+
+N = 1024
+
+
+def test_sample_extract_every_index_against_the_reference_product(O, keys128):
+    """trlwe.rs:106-120 at EVERY k: phase of the extracted sample == coefficient k of b - a (*) s computed with the
+    reference's Spqlios_poly_mul_1024, plus the count of wrapped positions with s_i = 1 (the MAX - x quirk)."""
+    if not O.ref_available():
+        pytest.skip("oracle/_ref not built (reference sources absent)")
+    sk, _ = keys128
+    rng = np.random.default_rng(41)
+    for _ in range(2):
+        a = (rng.integers(0, 2**24, N, dtype=np.uint64) * 256).astype(np.uint32)
+        b = rng.integers(0, 2**32, N, dtype=np.uint64).astype(np.uint32)
+        trlwe = np.stack([a, b])
+        exp = CF.extract_phase_expected(O, trlwe, sk.key_lv1)
+        got = np.array([CF.lv1_phase(O.sample_extract_index(trlwe, k), sk.key_lv1)[0] for k in range(N)], np.uint32)
+        assert np.array_equal(got, exp)
+        # what the identity pins: true negation instead of MAX - x is off by the wrapped count, the other rotation
+        # direction lands far away
+        true_neg = (exp - (sk.key_lv1.astype(np.int64).sum() - np.cumsum(sk.key_lv1.astype(np.int64))).astype(np.uint32)).astype(np.uint32)
+        assert not np.array_equal(got, true_neg)
+
+
+@pytest.mark.parametrize("setname,n", [("SECURITY_128_BIT", None), ("SECURITY_UINT4", None), ("SECURITY_UINT7", 96)])
+def test_key_switch_exact_phase_under_a_noise_free_key(O, setname, n):
+    """trgsw.rs:332-360 for base 4 / 32 / 128 (SECURITY_UINT7's base and t at a reduced n, so that the 1.8 GB key is not
+    built on the CPU suite): output phase == src.b - sum_i s1_i * trunc(a_i + PREC_OFFSET), exactly."""
+    import dataclasses
+
+    P = O.PARAM_SETS[setname]
+    if n:
+        P = dataclasses.replace(P, n=n)
+    sk = O.SecretKey(P, 77)
+    ksk = CF.noise_free_ksk(O, P, sk)
+    ck = O.CloudKey.from_arrays(P, np.zeros((P.n, 2 * P.l, 2, N)), ksk, 0, np.zeros((2, N), np.uint32))
+    rng = np.random.default_rng(42)
+    lv1 = rng.integers(0, 2**32, (6, N + 1), dtype=np.uint64).astype(np.uint32)
+    lv1[0, :N] = 0
+    lv1[1, :N] = 0xFFFFFFFF
+    out = np.stack([O.identity_key_switching(ck, x) for x in lv1])
+    got = sk.phase(out)
+    assert np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1))
+    # a wrong PREC_OFFSET (one bit too high / too low / absent), fails the identity: the decrypt-style test cannot see this
+    bits = P.basebit * P.t
+    for wrong in (1 << (32 - bits), 1 << (32 - (2 + bits)), 0):
+        assert not np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1, prec_offset=wrong))
