@@ -66,6 +66,12 @@ def parse():
                     help="time one stage entry point instead of the gate path: the reference's criterion groups "
                     "`bootstrapping` (= trgsw::blind_rotate) and `fft_operations` (benches/gate_benchmarks.rs:77-125)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target wall time of the CPU sample (whole thread sweep)")
+    ap.add_argument("--no-other-configs", action="store_true", help="N = 1: skip the short runs of BASELINE configs[3] / [4] and "
+                    "of the host-buffer path that the line carries as `other_configs`")
+    ap.add_argument("--no-pool-resident", action="store_true", help="N > 1: skip the single-process run of BASELINE configs[2] "
+                    "through ONE pool handle (batch resident on GPU 0, shards moved by RCCL) that the line carries as `pool_resident`")
+    ap.add_argument("--oracle-sample", type=int, default=0, help="with --pool-devices --resident: hold the first K results to the "
+                    "CPU path word for word (under the key exported from member 0)")
     return ap.parse_args()
 
 
@@ -242,6 +248,17 @@ def pool_resident_mode(args, R, pool, sk, devices, B, keygen_s):
         ok = bool(np.array_equal(sk.decrypt_bool(out), GATE_TRUTH[args.gate](bits[0], bits[1])))
         boots = B
     calls = max(1, tt["calls"])
+    oracle_equal, oracle_n = None, 0
+    if args.oracle_sample > 0 and args.gate != "mixed":
+        # the CPU path under the SAME key (exported from member 0), on the first K ciphertexts: checker only
+        from oracle import oracle as O
+
+        xk = pool.export_cloud_key(0)
+        ock = O.CloudKey.from_arrays(O.PARAM_SETS[args.params], xk.bootstrapping_key, xk.key_switching_key,
+                                     xk.decomposition_offset, xk.blind_rotate_testvec)
+        oracle_n = min(args.oracle_sample, B)
+        ha, hb = (t[:oracle_n].cpu().numpy().view(np.uint32) for t in (ta, tb))
+        oracle_equal = bool(np.array_equal(O.batch_gate(ock, gate, ha, hb), out[:oracle_n]))
     print(json.dumps({
         "metric": f"gate-bootstraps/sec ({args.gate}, {args.params}), single process, tfhe_hip_pool_*_dev over a batch resident on device {devices[0]}",
         "value": round(boots * args.steps / elapsed, 1), "unit": "bootstraps/s", "devices": devices, "steps": args.steps,
@@ -249,7 +266,10 @@ def pool_resident_mode(args, R, pool, sk, devices, B, keygen_s):
         "resident_on": devices[0], "transport": pool.data_transport, "key_transport": pool.key_transport,
         # per pool call: the longest single shard transfer (transfers to different members overlap) and the sum over members
         "scatter_ms": round(tt["scatter_ms_max"], 3), "gather_ms": round(tt["gather_ms_max"], 3),
+        # sums over the members' own brackets (under RCCL between distinct devices each is bounded only by its call's group
+        # time: an upper bound, not a per-link cost), and the home stream's bracket around each call's whole group
         "scatter_ms_sum_per_call": round(tt["scatter_ms_sum"] / calls, 3), "gather_ms_sum_per_call": round(tt["gather_ms_sum"] / calls, 3),
+        "scatter_group_ms": round(tt["scatter_group_ms_sum"] / calls, 3), "gather_group_ms": round(tt["gather_group_ms_sum"] / calls, 3),
         "scatter_MB_per_call": round(tt["scatter_bytes"] / calls / 1e6, 1), "gather_MB_per_call": round(tt["gather_bytes"] / calls / 1e6, 1),
         "pool_calls": tt["calls"],
         # set-up, each on its own (host wall clock): key generation on member 0, the communicator's creation
@@ -259,6 +279,7 @@ def pool_resident_mode(args, R, pool, sk, devices, B, keygen_s):
         # members that share a device exchange their shards by on-device copies: the times above then say nothing about
         # xGMI (a pool of distinct devices is what they are for)
         "transfers_cross_devices": len(set(devices)) == len(devices) and len(devices) > 1,
+        "oracle_sample_equal": oracle_equal, "oracle_sample": oracle_n,
         "decrypt_ok": ok}), flush=True)
 
 
@@ -377,6 +398,46 @@ def concurrent_single_gates(target, gate, ca, cb, threads=(1, 8, 64, 256), secon
     return {"threads": list(threads), "gates_per_s": rates, "call_ms_median": med,
             "unmerged_gates_per_s_8_threads": round(T * K / secs, 1),
             "what": "T host threads, one-ciphertext hom_nand calls with host buffers on one context, back to back"}
+
+
+def child_line(argv, env_extra=None, timeout=300):
+    """bench.py again as a FRESH child process (never an exec of this one: it has touched the GPU) with a hard timeout;
+    the one JSON line it prints, or {"error": ...}.  The launcher's rendezvous variables are not passed on."""
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                        "GROUP_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMP_NUM_THREADS", "BENCH_SHARE_GPU")
+           and not k.startswith("TORCHELASTIC_")}
+    env.update(env_extra or {})
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + [str(a) for a in argv], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout} s", "argv": [str(a) for a in argv]}
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    if p.returncode != 0 or len(lines) != 1:
+        return {"error": f"rc {p.returncode}", "argv": [str(a) for a in argv], "stderr_tail": p.stderr[-600:]}
+    return json.loads(lines[0])
+
+
+def other_configs(args):
+    """What BASELINE.json names beside configs[1], as short runs of their own (fresh child processes, three timed steps
+    each): configs[3] (LutBootstrap::bootstrap_lut, SECURITY_UINT4, m = 16), the single-GPU share of configs[4] (half
+    Gates::mux + half hom_xor, SECURITY_80_BIT), and the reference's own call shape -- host slices in, Vec out
+    (src/gates.rs:352-383) -- through the pool handle with pageable and with pinned buffers."""
+    out = {}
+    for name, argv in (("configs3_pbs_uint4", ["--gate", "pbs", "--params", "SECURITY_UINT4"]),
+                       ("configs4_share_mixed_80bit", ["--gate", "mixed", "--params", "SECURITY_80_BIT"])):
+        d = child_line(["--gpus", 1, "--steps", 3, "--warmup", 1, "--batch", args.batch, "--no-cpu-baseline", "--no-other-configs"] + argv)
+        out[name] = d if "error" in d else {
+            "metric": d["metric"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+            "decrypt_ok": d["decrypt_ok"], "roofline_frac": d["roofline"]["frac"], "roofline_kernel": d["roofline"]["kernel"],
+            "avg_launch_ms": d["roofline"]["avg_launch_ms"], "key_switch_avg_launch_ms": d["roofline"]["key_switch_avg_launch_ms"],
+            "dispatch": d["roofline"]["dispatch"], "workload": d["config"]["workload"]}
+    for name, extra in (("host_path_pageable", []), ("host_path_pinned", ["--pinned"])):
+        d = child_line(["--pool-devices", 0, "--steps", 2, "--warmup", 1, "--batch", args.batch, "--params", args.params,
+                        "--gate", args.gate] + extra)
+        out[name] = d if "error" in d else {k: d[k] for k in ("metric", "value", "unit", "ms_per_step", "host_memory", "pcie_inclusive", "decrypt_ok")}
+    return out
 
 
 def free_port() -> int:
@@ -587,8 +648,12 @@ def main():
         flag = torch.tensor([1 if decrypt_ok else 0], dtype=torch.int32, device="cpu" if share else dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         decrypt_ok = bool(flag.item())
+    key_broadcast_backend = dist.get_backend() if world > 1 else None
     if rank != 0:
         if world > 1:
+            pool.close()  # give the GPU back before rank 0 starts the pool-resident child
+            if not args.no_pool_resident:
+                dist.barrier()
             dist.destroy_process_group()
         return
 
@@ -786,6 +851,34 @@ def main():
             "gpu_matches_cpu_bit_exact": bool(np.array_equal(ref, out[:len(ref)])),
         }
 
+    others = None
+    if world == 1 and not args.no_other_configs and not special and args.params == "SECURITY_128_BIT":
+        pool.close()  # (the children use this GPU: give the key and the staging back first)
+        del ta, tb, to
+        torch.cuda.empty_cache()
+        others = other_configs(args)
+    resident = None
+    if world > 1 and not args.no_pool_resident:
+        # BASELINE configs[2] as its text has it -- "sharded across 8 x MI355X via RCCL over xGMI": ONE caller, ONE pool
+        # handle over all N devices, the GLOBAL batch resident on GPU 0, shards scattered / gathered by grouped
+        # ncclSend / ncclRecv (tfhe_hip_pool_batch_gate_dev; src/gates.rs:357-383 is the call it replaces).  The ranks
+        # have finished: they leave the process group and give their contexts back, then rank 0 alone starts a fresh
+        # child with a hard timeout.  The headline above never depends on it.
+        n_dev = torch.cuda.device_count()
+        devs = ",".join(str(r % n_dev) for r in range(world)) if share else ",".join(str(r) for r in range(world))
+        dist.barrier()
+        dist.destroy_process_group()
+        pool.close()
+        del ta, tb, to
+        torch.cuda.empty_cache()
+        d = child_line(["--pool-devices", devs, "--resident", "--steps", min(args.steps, 3), "--warmup", 1, "--batch", B,
+                        "--params", args.params, "--gate", args.gate if args.gate in ("mixed",) or not special else "nand",
+                        "--oracle-sample", 16], {"TFHE_HIP_POOL_RCCL": "1"}, timeout=420)
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "batch_total", "devices", "transport", "key_transport", "scatter_ms",
+                "gather_ms", "scatter_group_ms", "gather_group_ms", "scatter_MB_per_call", "gather_MB_per_call", "comm_create_s",
+                "key_replication_s", "transfers_cross_devices", "decrypt_ok", "oracle_sample_equal", "oracle_sample")
+        resident = d if "error" in d else {k: d.get(k) for k in keep}
+
     line = {
         "metric": f"gate-bootstraps/sec (hom_{args.gate}, {args.params})" if not special else
                   f"gate-bootstraps/sec ({args.gate}, {args.params})",
@@ -809,19 +902,21 @@ def main():
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
+        "other_configs": others,
+        "pool_resident": resident,
         "decrypt_ok": decrypt_ok,
         "setup_s": round(setup_s, 1),
         "keygen_s": round(keygen_s, 3),
         # N > 1: how the one key reached the other ranks' GPUs and how long that took (max over ranks); the data path
         # itself has no collective
         "key_broadcast_s": round(max(per_rank["key_broadcast_s"]), 3) if per_rank else None,
-        "key_broadcast_backend": (dist.get_backend() if world > 1 else None),
+        "key_broadcast_backend": key_broadcast_backend,
         "per_rank": per_rank,
         "ms_per_step_min_rank": min(per_rank["ms_per_step"]) if per_rank else None,
         "ms_per_step_max_rank": max(per_rank["ms_per_step"]) if per_rank else None,
     }
     print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -564,6 +564,11 @@ typedef struct tfhe_hip_pool_transfer_times {
   uint64_t scatter_bytes, gather_bytes;
   uint64_t calls; /* *_dev pool calls since the last read */
   double comm_create_ms, key_replication_ms;
+  /* RCCL path: the home stream's bracket around each call's WHOLE group (every peer's transfer; for a gather also the
+   * wait for the slowest member's compute), summed over calls -- an upper bound of any one transfer in the group.  Under
+   * RCCL between distinct devices a shard's figure above is bounded by it, so *_ms_sum can approach (members - 1) x this:
+   * read per-link cost from *_ms_max and the byte counts, not from the sums.  0 on the peer-copy path. */
+  double scatter_group_ms_sum, gather_group_ms_sum;
 } tfhe_hip_pool_transfer_times;
 int tfhe_hip_pool_set_profiling(tfhe_hip_pool *pool, int enabled);
 int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *pool, tfhe_hip_pool_transfer_times *out);

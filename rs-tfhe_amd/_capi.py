@@ -50,7 +50,8 @@ class PoolTransferTimes(C.Structure):
 
     _fields_ = [("scatter_ms_sum", C.c_double), ("scatter_ms_max", C.c_double), ("gather_ms_sum", C.c_double),
                 ("gather_ms_max", C.c_double), ("scatter_bytes", C.c_uint64), ("gather_bytes", C.c_uint64),
-                ("calls", C.c_uint64), ("comm_create_ms", C.c_double), ("key_replication_ms", C.c_double)]
+                ("calls", C.c_uint64), ("comm_create_ms", C.c_double), ("key_replication_ms", C.c_double),
+                ("scatter_group_ms_sum", C.c_double), ("gather_group_ms_sum", C.c_double)]
 
 
 class CombineStats(C.Structure):

@@ -6,27 +6,39 @@
 // workgroup on one of 256 CUs for 2.2 ms, so calls that ran one after the other would leave the chip 99.6 % idle
 // however many threads were waiting.  The front end merges them:
 //
-//   * a small call (count <= max_count) does not take the context's mutex; it joins a queue;
-//   * the call at the head of the queue, when a LANE is free, becomes the leader of that lane: it takes everything
-//     that queued up while the previous launches ran (natural batching), packs the operands into the lane's pinned
-//     arena, issues ONE launch per (key view, operation class) -- per-ciphertext gate codes and per-ciphertext test
-//     vectors already exist in the kernels (tfhe_hip_batch_gates_mixed, per_ct test vectors) --, hands every caller
-//     its slice of the result and wakes them;
+//   * a small call (count <= max_count) does not take the context's mutex; it pushes itself onto a lock-free arrival
+//     list and, if a LANE is free, becomes that lane's leader: it takes everything that has arrived -- in particular
+//     everything that arrived while the previous launch ran (natural batching) --, packs the operands into the lane's
+//     pinned arena, issues ONE launch per (key view, operation class) -- per-ciphertext gate codes and per-ciphertext
+//     test vectors already exist in the kernels (tfhe_hip_batch_gates_mixed, per_ct test vectors) --, hands every
+//     caller its rows of the result, marks the requests done and wakes the sleepers; everybody else sleeps on one
+//     futex word until its request is done or a lane is free;
 //   * a lane is a private sibling context (its own stream, scratch and staging; the caller's key is bound to it per
-//     launch), so two merged launches can be in flight beside each other and beside a large call on the context's
-//     own stream;
+//     launch), so a merged launch runs beside a large call on the context's own stream;
 //   * a leader that follows a merged launch closely waits a bounded moment for the callers of that launch to come back
 //     (they were all released at the same instant; without this the first one back would launch alone and the rest
 //     would wait a whole launch behind it).  A lone caller never waits: it leads at once and sees the latency of a
 //     plain one-ciphertext call.
+//
+// Lanes.  The machinery takes up to four lanes; ONE is used.  Two lanes let a second merged launch start while the
+// first is in flight, which only pays while both are small, and only if their streams land on different hardware
+// queues: measured on MI355X (profiles/exp/logs/r6b_front_end.log), 64 threads get 25-26 k gates/s on one lane and the
+// same on two lanes when the launches overlap -- but when the runtime maps the two streams to one hardware queue (it
+// hands out four per process and shares beyond that; seen whenever the second lane was created later than the first)
+// the launches run one after the other and every call takes two launch times: 14-15 k gates/s.  One lane cannot lose
+// that lottery.  (-DTFHE_EXPERIMENT builds read TFHE_HIP_COMBINE_LANES.)
 //
 // Same kernels, same per-element operations in the same order as the unmerged call: the results are the same bits
 // (tests/test_gpu_combine.py holds every word to the CPU checker).  Errors stay per calling thread: argument errors
 // are found by the caller before it queues, and a failure of the merged launch is copied into every request it carried
 // and filed under the calling thread's own error text.
 #pragma once
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+
 #include <chrono>
-#include <deque>
+#include <climits>
 #include <thread>
 
 struct CombReq {
@@ -42,34 +54,48 @@ struct CombReq {
   size_t count = 0;
   int rc = TFHE_HIP_OK;
   std::string err;
-  bool done = false;
+  // QUEUED until a leader takes it, DONE when its rows are in `out` (or rc / err say why not).  The owner's frame may
+  // go away the moment it reads DONE: a leader does not touch a request after storing that.
+  enum : uint32_t { QUEUED = 0, TAKEN = 1, DONE = 2 };
+  std::atomic<uint32_t> state{QUEUED};
+  CombReq *next = nullptr;  // the arrival list (newest first)
 };
 
+// No mutex on the callers' path: with hundreds of threads released at the same instant by one merged launch, a
+// condition variable's mutex is re-acquired by every one of them in turn (measured: a 256-thread team spent as long in
+// that queue as in the launch).  Arrivals push themselves onto a lock-free list, lanes are bits of one word, and
+// everybody who has to wait sleeps on ONE futex word (`epoch`) that is bumped whenever something completes or a lane
+// becomes free; woken threads look at their own request's state and go back to sleep if it is not their turn.
 struct Combiner {
   static constexpr int kLanes = 4;  // most lanes a front end can have
-  int nlanes = 2;                   // lanes in use
   static constexpr size_t kBatchCap = 4096;  // ciphertexts per merged launch (bounds the pinned arenas)
+  int nlanes = 1;                   // lanes in use (see the note on lanes below)
   struct Lane {
     tfhe_hip_ctx *x = nullptr;  // created by its first leader
-    bool busy = false;
-    uint64_t gen = 0;  // merged launches completed on this lane
+    std::atomic<uint64_t> gen{0};  // leader rounds completed on this lane
   };
-  std::mutex mu;
-  std::condition_variable cv;
-  std::deque<CombReq *> q;
   Lane lane[kLanes];
+  std::atomic<CombReq *> arrivals_head{nullptr};
+  std::atomic<uint32_t> lanes_busy{0};  // bit i: lane i has a leader
+  std::atomic<uint32_t> epoch{0};       // the futex word
+  std::atomic<uint32_t> sleepers{0};    // threads in (or about to enter) futex_wait: nobody to wake, no system call
+  std::atomic<uint32_t> collecting{0};  // leaders between taking a lane and taking the arrival list: arrivals do not lead, they will be taken
   std::atomic<size_t> max_count{0};  // calls of up to this many ciphertexts are merged; 0 = front end off
   std::atomic<size_t> pending{0};    // ciphertexts queued or in flight (a pool picks its least loaded member by it)
   std::atomic<uint64_t> arrivals{0};  // requests ever queued (the lingering leader watches it grow)
-  bool profiling = false;             // what lanes created later start with
-  // the last merged launch that completed: how many requests it carried, and when
-  size_t last_reqs = 0;
-  std::chrono::steady_clock::time_point last_done{};
-  // lingering (see the header comment): only within kLingerWindow of a merged launch that carried several requests;
-  // ends when as many requests are queued as that launch carried, when nobody has arrived for kLingerQuiet, or after
-  // kLingerMax
+  std::atomic<uint64_t> taken{0};     // requests ever taken by a leader
+  std::atomic<bool> profiling{false};  // what lanes created later start with
+  // the last leader round that completed: how many requests it carried, and when (steady_clock ns)
+  std::atomic<size_t> last_reqs{0};
+  std::atomic<int64_t> last_done_ns{0};
+  // lingering (see the header comment): only within linger_window of a round that carried several requests; ends when
+  // as many requests are waiting as that round carried (`want`), when nobody has arrived for linger_quiet + want / 4
+  // microseconds, or after linger_max + want microseconds (a team of hundreds of threads takes that long to come back
+  // through the scheduler; a launch that leaves without most of them makes them wait a whole launch: measured at 256
+  // threads, 41 k gates/s with a 10 us quiet gap, 65 k with 100 us -- profiles/exp/logs/r6b_front_end.log)
   long linger_window_us = 1000, linger_quiet_us = 25, linger_max_us = 250;
-  // statistics (tfhe_hip_get_combine_stats)
+  // statistics (tfhe_hip_get_combine_stats); leaders only
+  std::mutex st_mu;
   uint64_t st_launches = 0, st_requests = 0, st_cts = 0, st_max_requests = 0, st_lingers = 0;
   double st_linger_us = 0;
 };
@@ -197,74 +223,111 @@ int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, Combiner::Lane &L, std::stri
   x->br_chunk = base->br_chunk;
   x->exp_wide1 = base->exp_wide1;
   x->fast_round = base->fast_round;
-  x->profiling = C.profiling;
+  x->profiling = C.profiling.load(std::memory_order_relaxed);
   L.x = x;
   return TFHE_HIP_OK;
 }
 
-// The calling thread leads lane `li`: C.mu held on entry and on return, released while the launch runs.  `me` is at
-// the head of the queue, so it is part of what is taken.
-void comb_lead(tfhe_hip_ctx *base, Combiner &C, int li, std::unique_lock<std::mutex> &lk) {
-  using clock = std::chrono::steady_clock;
+// ---- waiting and waking: one futex word ---------------------------------------------------------------------------
+inline void comb_wait(Combiner &C, uint32_t seen) {
+  C.sleepers.fetch_add(1, std::memory_order_seq_cst);
+  if (C.epoch.load(std::memory_order_seq_cst) == seen)
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&C.epoch), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
+  C.sleepers.fetch_sub(1, std::memory_order_seq_cst);
+}
+inline void comb_wake_all(Combiner &C) {
+  C.epoch.fetch_add(1, std::memory_order_seq_cst);
+  if (C.sleepers.load(std::memory_order_seq_cst))
+    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&C.epoch), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+}
+inline int comb_try_lane(Combiner &C) {  // a free lane, now this thread's; -1: none
+  uint32_t busy = C.lanes_busy.load(std::memory_order_relaxed);
+  for (;;) {
+    int li = -1;
+    for (int i = 0; i < C.nlanes && li < 0; ++i)
+      if (!(busy & (1u << i))) li = i;
+    if (li < 0) return -1;
+    if (C.lanes_busy.compare_exchange_weak(busy, busy | (1u << li), std::memory_order_acquire, std::memory_order_relaxed)) return li;
+  }
+}
+inline void comb_release_lane(Combiner &C, int li) {
+  C.lane[li].gen.fetch_add(1, std::memory_order_release);
+  C.lanes_busy.fetch_and(~(1u << li), std::memory_order_release);
+  comb_wake_all(C);
+}
+inline int64_t comb_now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The calling thread holds lane `li`: it takes whatever has arrived, runs it, marks it done and releases the lane.
+void comb_lead(tfhe_hip_ctx *base, Combiner &C, int li) {
   Combiner::Lane &L = C.lane[li];
-  L.busy = true;
-  // the callers of the merged launch that has just completed are on their way back: give them a bounded moment
-  if (C.last_reqs > 1 && C.q.size() < C.last_reqs && clock::now() - C.last_done < std::chrono::microseconds(C.linger_window_us)) {
-    const size_t want = C.last_reqs;
-    const uint64_t arrived0 = C.arrivals.load(std::memory_order_relaxed);
-    const size_t queued0 = C.q.size();
-    lk.unlock();
-    const auto t0 = clock::now();
-    auto last_growth = t0;
-    uint64_t seen = arrived0;
-    for (;;) {
-      cpu_relax();
-      const auto now = clock::now();
-      const uint64_t cur = C.arrivals.load(std::memory_order_relaxed);
-      if (cur != seen) {
-        seen = cur;
-        last_growth = now;
-      }
-      if (queued0 + (size_t)(cur - arrived0) >= want) break;
-      if (now - last_growth > std::chrono::microseconds(C.linger_quiet_us)) break;
-      if (now - t0 > std::chrono::microseconds(C.linger_max_us)) break;
-    }
-    lk.lock();
-    ++C.st_lingers;
-    C.st_linger_us += std::chrono::duration<double, std::micro>(clock::now() - t0).count();
-  }
-  std::vector<CombReq *> batch;
-  size_t total = 0;
-  while (!C.q.empty() && (batch.empty() || total + C.q.front()->count <= Combiner::kBatchCap)) {
-    batch.push_back(C.q.front());
-    total += C.q.front()->count;
-    C.q.pop_front();
-  }
-  lk.unlock();
-  size_t launches = 0;
+  C.collecting.fetch_add(1, std::memory_order_seq_cst);
+  // the callers of the round that has just completed are on their way back: give them a bounded moment
   {
+    const size_t want = C.last_reqs.load(std::memory_order_relaxed);
+    const uint64_t taken0 = C.taken.load(std::memory_order_relaxed);
+    auto waiting = [&] { return (size_t)(C.arrivals.load(std::memory_order_relaxed) - taken0); };
+    const int64_t t0 = comb_now_ns();
+    if (want > 1 && waiting() < want && t0 - C.last_done_ns.load(std::memory_order_relaxed) < C.linger_window_us * 1000) {
+      int64_t last_growth = t0, now = t0;
+      size_t seen = waiting();
+      for (;;) {
+        cpu_relax();
+        now = comb_now_ns();
+        const size_t cur = waiting();
+        if (cur != seen) {
+          seen = cur;
+          last_growth = now;
+        }
+        if (cur >= want || now - last_growth > (C.linger_quiet_us * 4 + (long)want) * 250 || now - t0 > (C.linger_max_us + (long)want) * 1000) break;
+      }
+      std::lock_guard<std::mutex> lk(C.st_mu);
+      ++C.st_lingers;
+      C.st_linger_us += (double)(now - t0) * 1e-3;
+    }
+  }
+  // take the arrival list (newest first) and put it in arrival order
+  std::vector<CombReq *> all;
+  for (CombReq *r = C.arrivals_head.exchange(nullptr, std::memory_order_acquire); r;) {
+    CombReq *nx = r->next;  // (read before anything can complete the request)
+    all.push_back(r);
+    r = nx;
+  }
+  std::reverse(all.begin(), all.end());
+  C.taken.fetch_add(all.size(), std::memory_order_relaxed);
+  for (CombReq *r : all) r->state.store(CombReq::TAKEN, std::memory_order_seq_cst);
+  C.collecting.fetch_sub(1, std::memory_order_seq_cst);
+  // a request that arrived after the list was taken may have seen `collecting` and gone to sleep expecting to be taken
+  if (C.arrivals_head.load(std::memory_order_seq_cst)) comb_wake_all(C);
+  size_t launches = 0, total = 0;
+  if (!all.empty()) {
     DeviceGuard dg(base->device);
     std::string why;
     int rc = dg.err == hipSuccess ? TFHE_HIP_OK : TFHE_HIP_EHIP;
     if (rc != TFHE_HIP_OK) why = std::string("hipSetDevice: ") + hipGetErrorString(dg.err);
     if (rc == TFHE_HIP_OK && !L.x) rc = comb_make_lane(base, C, L, why);
     if (rc != TFHE_HIP_OK) {
-      for (CombReq *r : batch) {
+      for (CombReq *r : all) {
         r->rc = rc;
         r->err = why;
       }
     } else {
-      // groups: (key view, class, key switch or not, own test vector or not), each in queue order
-      std::vector<bool> taken(batch.size(), false);
-      for (size_t i = 0; i < batch.size(); ++i) {
-        if (taken[i]) continue;
-        const CombReq &h = *batch[i];
+      // groups: (key view, class, key switch or not, own test vector or not), each in arrival order and cut at
+      // kBatchCap ciphertexts
+      std::vector<bool> placed(all.size(), false);
+      for (size_t i = 0; i < all.size(); ++i) {
+        if (placed[i]) continue;
+        const CombReq &h = *all[i];
         std::vector<CombReq *> g;
-        for (size_t j = i; j < batch.size(); ++j) {
-          const CombReq &r = *batch[j];
-          if (taken[j] || r.key != h.key || r.cls != h.cls || r.keyswitch != h.keyswitch || (r.testvec != nullptr) != (h.testvec != nullptr)) continue;
-          taken[j] = true;
-          g.push_back(batch[j]);
+        size_t m = 0;
+        for (size_t j = i; j < all.size(); ++j) {
+          const CombReq &r = *all[j];
+          if (placed[j] || r.key != h.key || r.cls != h.cls || r.keyswitch != h.keyswitch || (r.testvec != nullptr) != (h.testvec != nullptr)) continue;
+          if (!g.empty() && m + r.count > Combiner::kBatchCap) break;  // the rest of this group: a launch of its own
+          placed[j] = true;
+          g.push_back(all[j]);
+          m += r.count;
         }
         const int grc = comb_run_group(L.x, h.key, g);
         ++launches;
@@ -277,37 +340,45 @@ void comb_lead(tfhe_hip_ctx *base, Combiner &C, int li, std::unique_lock<std::mu
         }
       }
     }
+    for (CombReq *r : all) total += r->count;
+    C.pending.fetch_sub(total, std::memory_order_relaxed);
+    C.last_reqs.store(all.size(), std::memory_order_relaxed);
+    C.last_done_ns.store(comb_now_ns(), std::memory_order_relaxed);
+    {
+      std::lock_guard<std::mutex> lk(C.st_mu);
+      C.st_launches += launches;
+      C.st_requests += all.size();
+      C.st_cts += total;
+      if (all.size() > C.st_max_requests) C.st_max_requests = all.size();
+    }
+    for (CombReq *r : all) r->state.store(CombReq::DONE, std::memory_order_release);  // (r may be gone after this)
   }
-  lk.lock();
-  for (CombReq *r : batch) r->done = true;
-  C.pending.fetch_sub(total, std::memory_order_relaxed);
-  L.busy = false;
-  ++L.gen;
-  C.last_reqs = batch.size();
-  C.last_done = clock::now();
-  C.st_launches += launches;
-  C.st_requests += batch.size();
-  C.st_cts += total;
-  if (batch.size() > C.st_max_requests) C.st_max_requests = batch.size();
-  C.cv.notify_all();
+  comb_release_lane(C, li);
 }
 
-// queue the request, lead if it is this thread's turn, return when the request has been served
+// queue the request, lead when a lane is free, return when the request has been served
 int comb_submit(tfhe_hip_ctx *base, CombReq &r) {
   Combiner &C = *base->comb;
+  C.pending.fetch_add(r.count, std::memory_order_relaxed);
   {
-    std::unique_lock<std::mutex> lk(C.mu);
-    C.q.push_back(&r);
-    C.pending.fetch_add(r.count, std::memory_order_relaxed);
-    C.arrivals.fetch_add(1, std::memory_order_relaxed);
-    while (!r.done) {
-      int free_lane = -1;
-      if (C.q.front() == &r)
-        for (int i = 0; i < C.nlanes && free_lane < 0; ++i)
-          if (!C.lane[i].busy) free_lane = i;
-      if (free_lane >= 0) comb_lead(base, C, free_lane, lk);
-      else C.cv.wait(lk);
+    CombReq *h = C.arrivals_head.load(std::memory_order_relaxed);
+    do r.next = h;
+    while (!C.arrivals_head.compare_exchange_weak(h, &r, std::memory_order_release, std::memory_order_relaxed));
+  }
+  C.arrivals.fetch_add(1, std::memory_order_relaxed);
+  for (;;) {
+    const uint32_t e = C.epoch.load(std::memory_order_seq_cst);  // (before the checks: a wake-up in between is not lost)
+    const uint32_t st = r.state.load(std::memory_order_acquire);
+    if (st == CombReq::DONE) break;
+    if (st == CombReq::QUEUED && C.collecting.load(std::memory_order_seq_cst) == 0) {
+      const int li = comb_try_lane(C);
+      if (li >= 0) {
+        if (r.state.load(std::memory_order_seq_cst) == CombReq::QUEUED) comb_lead(base, C, li);  // takes this request too
+        else comb_release_lane(C, li);  // another leader took it meanwhile
+        continue;
+      }
     }
+    comb_wait(C, e);
   }
   if (r.rc != TFHE_HIP_OK) err_slot(base->id) = r.err;
   return r.rc;
@@ -324,10 +395,13 @@ inline bool comb_takes(const tfhe_hip_ctx *ctx, size_t count) {
 void comb_quiesce(tfhe_hip_ctx *base) {
   Combiner *C = base->comb;
   if (!C) return;
-  std::unique_lock<std::mutex> lk(C->mu);
   for (int i = 0; i < Combiner::kLanes; ++i) {
-    const uint64_t g = C->lane[i].gen;
-    C->cv.wait(lk, [&] { return !C->lane[i].busy || C->lane[i].gen != g; });
+    const uint64_t g = C->lane[i].gen.load(std::memory_order_acquire);
+    for (;;) {
+      const uint32_t e = C->epoch.load(std::memory_order_seq_cst);
+      if (!(C->lanes_busy.load(std::memory_order_acquire) & (1u << i)) || C->lane[i].gen.load(std::memory_order_acquire) != g) break;
+      comb_wait(*C, e);
+    }
   }
 }
 
@@ -336,13 +410,16 @@ template <class F>
 void comb_with_idle_lanes(tfhe_hip_ctx *base, F &&f) {
   Combiner *C = base->comb;
   if (!C) return;
-  std::unique_lock<std::mutex> lk(C->mu);
-  C->cv.wait(lk, [&] {
-    for (int i = 0; i < Combiner::kLanes; ++i)
-      if (C->lane[i].busy) return false;
-    return true;
-  });
+  const uint32_t all = (1u << Combiner::kLanes) - 1;
+  for (;;) {  // take every lane bit at once
+    const uint32_t e = C->epoch.load(std::memory_order_seq_cst);
+    uint32_t none = 0;
+    if (C->lanes_busy.compare_exchange_strong(none, all, std::memory_order_acquire, std::memory_order_relaxed)) break;
+    comb_wait(*C, e);
+  }
   f(*C);
+  C->lanes_busy.store(0, std::memory_order_release);
+  comb_wake_all(*C);
 }
 
 void comb_destroy(tfhe_hip_ctx *base) {

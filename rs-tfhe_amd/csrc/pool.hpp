@@ -27,6 +27,7 @@ struct tfhe_hip_pool {
   // ---- root only: what the device-resident (_dev) calls and the key replication share ----
   std::vector<ncclComm_t> comms;    // ONE persistent communicator per pool (created on first use, destroyed with the pool)
   int comm_state = 0;               // 0 = not tried yet, 1 = ready, -1 = unavailable (duplicate devices, no librccl, init failed)
+  bool comms_dropped = false;       // a group failed half-way (pool_drop_comms): streams it touched may never drain
   struct Stage {                    // per member: staging for shards that arrive from / leave for another member's GPU
     DevBuf in[5], out;
     hipEvent_t done = nullptr;      // recorded on the member's stream when its shard's result has left
@@ -45,6 +46,7 @@ struct tfhe_hip_pool {
     hipEvent_t a = nullptr, b = nullptr;
     int member = 0;    // whose device the events live on
     long home_ix = -1;  // RCCL: the call's home-stream pair
+    bool gather = false;  // (ev_home) which direction's group this pair brackets
   };
   bool timing = false;
   std::vector<Timed> ev_scatter, ev_gather, ev_home;
@@ -189,10 +191,13 @@ void pool_drop_comms(tfhe_hip_pool *p) {
   tfhe_hip_pool *root = p->root();
   if (root->comm_state != 1) return;
   RcclApi &R = rccl_api();
+  // (no ncclCommAbort in this librccl: the communicators are LEAKED -- ncclCommDestroy waits for outstanding work, and a
+  // send whose receive was never launched would hang the caller here, with the pool's mutex held)
   for (ncclComm_t c : root->comms)
-    if (c) (void)(R.CommAbort ? R.CommAbort(c) : R.CommDestroy(c));
+    if (c && R.CommAbort) (void)R.CommAbort(c);
   root->comms.clear();
   root->comm_state = -1;
+  root->comms_dropped = true;
   (void)hipGetLastError();
 }
 
@@ -568,6 +573,7 @@ int pool_dev_map(tfhe_hip_pool *p, int home, size_t count, void *stream_v, const
       // brackets the transfer and whatever it waits for on the home side); one pair on the home stream around the
       // group's receives (which also waits for the slowest member's result)
       const long hix = timed_begin(root->ev_home, home, hrt);
+      if (hix >= 0) root->ev_home[(size_t)hix].gather = true;
       std::vector<long> gix(shards.size(), -1);
       for (size_t q = 0; q < shards.size(); ++q)
         if (shards[q].remote) gix[q] = timed_begin(root->ev_gather, shards[q].member, member_stream(shards[q].member), hix);
@@ -688,8 +694,9 @@ void tfhe_hip_pool_destroy(tfhe_hip_pool *p) {
   int prev = -1;
   (void)hipGetDevice(&prev);
   // queued device-resident calls may still use the staging buffers and the communicator: drain the members first
+  // (not after a group failed half-way: a stream that carries a send without its receive never drains)
   for (auto *c : p->ctxs) {
-    if (hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
+    if (!p->comms_dropped && hipSetDevice(c->device) == hipSuccess) (void)hipStreamSynchronize(c->stream);
   }
   if (p->comm_state == 1)
     for (ncclComm_t c : p->comms)
@@ -1111,6 +1118,10 @@ int tfhe_hip_pool_get_transfer_times(tfhe_hip_pool *p, tfhe_hip_pool_transfer_ti
   };
   drain(root->ev_scatter, out->scatter_ms_sum, out->scatter_ms_max);
   drain(root->ev_gather, out->gather_ms_sum, out->gather_ms_max);
+  // the home-stream brackets on their own: one per call and direction, around the whole RCCL group (all peers' transfers,
+  // and for a gather the wait for the slowest member's compute) -- an upper bound of any one transfer in it
+  for (size_t i = 0; i < root->ev_home.size(); ++i)
+    if (home_ms[i] >= 0) (root->ev_home[i].gather ? out->gather_group_ms_sum : out->scatter_group_ms_sum) += home_ms[i];
   for (auto &t : root->ev_home) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);

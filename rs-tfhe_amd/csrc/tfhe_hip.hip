@@ -2158,7 +2158,7 @@ int tfhe_hip_get_combine_stats(tfhe_hip_ctx *ctx, tfhe_hip_combine_stats *out) {
   memset(out, 0, sizeof(*out));
   Combiner *C = base->comb;
   if (!C) return TFHE_HIP_OK;
-  std::lock_guard<std::mutex> lk(C->mu);
+  std::lock_guard<std::mutex> lk(C->st_mu);
   out->max_count = C->max_count.load(std::memory_order_relaxed);
   out->launches = C->st_launches;
   out->requests = C->st_requests;

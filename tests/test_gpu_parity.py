@@ -1851,6 +1851,31 @@ def test_bench_eight_ranks_share_one_gpu():
         assert d["ms_per_step_max_rank"] == max(pr["ms_per_step"]) and d["ms_per_step_min_rank"] > 0
         assert d["ms_per_step"] >= d["ms_per_step_max_rank"] - 0.01  # the line's time is the max over ranks
         assert d["key_broadcast_s"] > 0 and d["key_broadcast_backend"] == "gloo"
+        # BASELINE configs[2] as one caller has it: ONE pool handle over the eight members, the GLOBAL batch resident on
+        # member 0's GPU (a fresh child of rank 0, after the ranks have let go of the GPU); here the members share a
+        # device, so the shards move by peer copies
+        pr = d["pool_resident"]
+        assert "error" not in pr, pr
+        assert pr["batch_total"] == 8192 and len(pr["devices"]) == 8 and pr["transport"] == "peer-copy" and pr["value"] > 0
+        if not extra:
+            assert pr["decrypt_ok"] is True and pr["oracle_sample_equal"] is True and pr["oracle_sample"] == 16
+
+
+def test_bench_line_carries_the_other_configs_and_the_concurrent_callers():
+    """The N = 1 line (what the driver records as BENCH_rNN) beside its headline: short runs of BASELINE configs[3] and
+    of configs[4]'s single-GPU share, the host-buffer path pageable and pinned, and the aggregate rate of a team of
+    threads making one-ciphertext calls (cpu_baseline.gpu_concurrent_single_gate)."""
+    d = _run_bench(["--steps", "2", "--warmup", "1", "--batch", "4096", "--cpu-seconds", "3"], {}, timeout=1200)
+    oc = d["other_configs"]
+    for k in ("configs3_pbs_uint4", "configs4_share_mixed_80bit", "host_path_pageable", "host_path_pinned"):
+        assert "error" not in oc[k], oc[k]
+        assert oc[k]["value"] > 0 and oc[k]["decrypt_ok"] is True, oc[k]
+    assert "SECURITY_UINT4" in oc["configs3_pbs_uint4"]["metric"] and 0 < oc["configs3_pbs_uint4"]["roofline_frac"] < 1
+    assert "SECURITY_80_BIT" in oc["configs4_share_mixed_80bit"]["metric"]
+    cc = d["cpu_baseline"]["gpu_concurrent_single_gate"]
+    assert cc["threads"] == [1, 8, 64, 256] and len(cc["gates_per_s"]) == 4
+    assert cc["gates_per_s"][2] > 10 * cc["unmerged_gates_per_s_8_threads"], cc
+    assert d["cpu_baseline"]["gpu_matches_cpu_bit_exact"] is True and d["decrypt_ok"] is True
 
 
 def test_bench_pool_two_members_pinned_and_pageable():
