@@ -779,9 +779,16 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 namespace {
 inline bool pool_small(const tfhe_hip_pool *p, size_t count) { return p && !p->ctxs.empty() && comb_takes(p->ctxs[0], count); }
 inline tfhe_hip_ctx *pool_least_loaded(tfhe_hip_pool *p) {
+  // members that share a device count once (the first of them): two front ends on one GPU would launch on two streams that
+  // need not overlap, and every call would wait for the other member's launch (measured on a pool of {0, 0}: 1.5 k gates/s
+  // from 8 threads against 3.1 k through one member, profiles/exp/logs/r6c_front_end.log)
   tfhe_hip_ctx *best = p->ctxs[0];
   size_t best_load = ~(size_t)0;
-  for (tfhe_hip_ctx *c : p->ctxs) {
+  for (size_t i = 0; i < p->ctxs.size(); ++i) {
+    tfhe_hip_ctx *c = p->ctxs[i];
+    bool repeat = false;
+    for (size_t j = 0; j < i && !repeat; ++j) repeat = p->ctxs[j]->device == c->device;
+    if (repeat) continue;
     const tfhe_hip_ctx *base = c->parent ? c->parent : c;
     const size_t load = base->comb ? base->comb->pending.load(std::memory_order_relaxed) : 0;
     if (load < best_load) {

@@ -177,6 +177,12 @@ struct tfhe_hip_ctx {
   int ks_sl_kchunks = 0;      // 0: K chunks of the column-sliced kernel picked per launch; else forced (1 ... 64, a power of two)
   long br_chunk = 0;  // blind-rotate workgroups per launch: 0 = whole batch (default), -1 = resident set, N = N
   bool exp_wide1 = false;  // (experiment builds with -DTFHE_EXP_WIDE1: SINGLE runs the superseded one-wave-per-row kernel)
+  // experiment builds (profiles/exp/midsize.py): the two parts of a blind-rotation plan on TWO streams, and a forced cut
+  bool exp_overlap = false;
+  size_t exp_split_at = 0;
+  int exp_split_kind[2] = {0, 0};
+  hipStream_t exp_stream2 = nullptr;
+  hipEvent_t exp_ev[2] = {nullptr, nullptr};
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_br, ev_ks;
   uint64_t bootstraps = 0;
   hipStream_t scratch_owner = nullptr;  // stream whose queued work may still use lv1/u1/u2
@@ -481,8 +487,24 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
     HIPCHK(ctx, hipGetLastError());
     return record_end(ctx, s, ctx->ev_br);
   };
-  const BrPlan pl = plan_blind_rotate(ctx, count);
+  BrPlan pl = plan_blind_rotate(ctx, count);
+#ifdef TFHE_EXPERIMENT
+  if (ctx->exp_split_at && count > ctx->exp_split_at) {  // a forced cut: kind[0] over [0, at), kind[1] over the rest
+    pl = BrPlan();
+    pl.add((BrKind)ctx->exp_split_kind[0], 0, ctx->exp_split_at);
+    pl.add((BrKind)ctx->exp_split_kind[1], ctx->exp_split_at, count - ctx->exp_split_at);
+  }
+  const bool overlap = ctx->exp_overlap && pl.nparts == 2 && ctx->exp_stream2;
+  hipStream_t s_home = s;
+  if (overlap) {  // the second part may start as soon as what precedes this call on `s` is done
+    HIPCHK(ctx, hipEventRecord(ctx->exp_ev[0], s));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->exp_stream2, ctx->exp_ev[0], 0));
+  }
+#endif
   for (int q = 0; q < pl.nparts; ++q) {
+#ifdef TFHE_EXPERIMENT
+    if (overlap) s = q == 1 ? ctx->exp_stream2 : s_home;
+#endif
     const size_t begin = pl.begin[q], m_all = pl.count[q];
     if (pl.kind[q] == BR_PAIR) {
       CHK(launch(br_pair_kernel(ctx), (unsigned)((m_all + 1) / 2), 64u * kPairWaves, blind_rotate_pair_lds_bytes(ctx->P.n),
@@ -518,6 +540,12 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
       }
     }
   }
+#ifdef TFHE_EXPERIMENT
+  if (overlap) {  // whatever follows on the caller's stream waits for the second part
+    HIPCHK(ctx, hipEventRecord(ctx->exp_ev[1], ctx->exp_stream2));
+    HIPCHK(ctx, hipStreamWaitEvent(s_home, ctx->exp_ev[1], 0));
+  }
+#endif
   ctx->bootstraps += count;
   return TFHE_HIP_OK;
 }
@@ -1133,6 +1161,21 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if (const char *env = getenv("TFHE_HIP_PAIR_MAX")) ctx->pair_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_KS_SPLIT_MAX")) ctx->ks_split_max = (size_t)atol(env);
   if (const char *env = getenv("TFHE_HIP_BR_CHUNK")) ctx->br_chunk = atol(env);
+  if (const char *env = getenv("TFHE_HIP_BR_OVERLAP")) ctx->exp_overlap = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_BR_SPLIT")) {  // "<at>:<kind0>:<kind1>", kinds 0 batch / 1 single / 2 pair
+    unsigned long at = 0;
+    int k0 = 0, k1 = 0;
+    if (sscanf(env, "%lu:%d:%d", &at, &k0, &k1) == 3 && k0 >= 0 && k0 <= 2 && k1 >= 0 && k1 <= 2) {
+      ctx->exp_split_at = at;
+      ctx->exp_split_kind[0] = k0;
+      ctx->exp_split_kind[1] = k1;
+    }
+  }
+  if (ctx->exp_overlap) {
+    (void)hipStreamCreateWithFlags(&ctx->exp_stream2, hipStreamNonBlocking);
+    (void)hipEventCreateWithFlags(&ctx->exp_ev[0], hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&ctx->exp_ev[1], hipEventDisableTiming);
+  }
 #ifdef TFHE_EXP_WIDE1
   if (const char *env = getenv("TFHE_HIP_BR_WIDE2")) ctx->exp_wide1 = atoi(env) == 0;
 #endif

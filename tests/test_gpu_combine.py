@@ -79,8 +79,9 @@ def test_concurrent_lut_bootstraps_with_their_own_tables(O, eng128, keys128):
 
 
 def test_concurrent_single_gates_on_a_pool(O, eng128, keys128):
-    """The same team on a pool handle (two members on this box's GPU): small calls skip the pool's mutex, go to the least
-    loaded member and merge there."""
+    """The same team on a pool handle (two members on this box's GPU): small calls skip the pool's mutex and merge in the
+    front end of the least loaded member -- members that share a device count once, so here the first member takes
+    them all (tests/test_gpu_multi_device.py has the spread over distinct devices)."""
     import rs_tfhe_amd as R
     from rs_tfhe_amd import callers
 
@@ -97,8 +98,8 @@ def test_concurrent_single_gates_on_a_pool(O, eng128, keys128):
     out, secs, _ = callers.run(pool, callers.OP_GATE, ca, cb, gates=gates, threads=T, calls=K)
     st = pool.combine_stats()
     assert np.array_equal(out, _oracle_gates(O, ck, gates, ca, cb))
-    assert sum(s["requests"] for s in st) == T * K and all(s["requests"] > 0 for s in st), st  # both members took calls
-    assert sum(s["launches"] for s in st) * 4 <= T * K, st
+    assert st[0]["requests"] == T * K and st[1]["requests"] == 0, st
+    assert st[0]["launches"] * 8 <= T * K, st
     # mux through the pool, merged as well (three bootstraps each)
     Cc = rng.integers(0, 2, 48).astype(bool)
     cc = sk.encrypt_bool(Cc, 6006)
