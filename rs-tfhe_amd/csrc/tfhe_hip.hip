@@ -496,8 +496,10 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
   }
   const bool overlap = ctx->exp_overlap && pl.nparts == 2 && ctx->exp_stream2;
   hipStream_t s_home = s;
+  // (event and wait calls take the runtime's own name for the default stream, NULL: they fault on the hipStreamLegacy handle)
+  hipStream_t s_rt = s == hipStreamLegacy ? (hipStream_t) nullptr : s;
   if (overlap) {  // the second part may start as soon as what precedes this call on `s` is done
-    HIPCHK(ctx, hipEventRecord(ctx->exp_ev[0], s));
+    HIPCHK(ctx, hipEventRecord(ctx->exp_ev[0], s_rt));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->exp_stream2, ctx->exp_ev[0], 0));
   }
 #endif
@@ -543,7 +545,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
 #ifdef TFHE_EXPERIMENT
   if (overlap) {  // whatever follows on the caller's stream waits for the second part
     HIPCHK(ctx, hipEventRecord(ctx->exp_ev[1], ctx->exp_stream2));
-    HIPCHK(ctx, hipStreamWaitEvent(s_home, ctx->exp_ev[1], 0));
+    HIPCHK(ctx, hipStreamWaitEvent(s_rt, ctx->exp_ev[1], 0));
   }
 #endif
   ctx->bootstraps += count;

@@ -127,7 +127,9 @@ def test_key_replication_and_every_entry_point_over_distinct_devices(O, keys128,
     out, _, _ = callers.run(pool, callers.OP_GATE, ca[:n], cb[:n], gates=np.full(n, O.GATE_NAND, np.uint8), threads=T, calls=K)
     st = pool.combine_stats()
     assert np.array_equal(out, want["nand"][:n])
-    assert sum(s["requests"] for s in st) == n and sum(1 for s in st if s["requests"] > 0) >= 2, st
+    assert sum(s["requests"] for s in st) == n, st
+    if _distinct(devs):  # (members that share a device count once: a dry run on {0, 0} sends everything to the first)
+        assert sum(1 for s in st if s["requests"] > 0) >= 2, st
     single.close()
     pool.close()
 
