@@ -23,7 +23,7 @@
 #pragma once
 #include <type_traits>
 
-#include "../../rs-tfhe_amd/csrc/blind_rotate.hpp"
+#include "../../../rs-tfhe_amd/csrc/blind_rotate.hpp"
 
 namespace tfhe {
 

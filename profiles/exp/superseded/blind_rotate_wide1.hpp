@@ -6,7 +6,7 @@
 // parameter sets its 2L-term sums are ordered differently from the three shipped kernels, so its low bits differ
 // there -- one reason it was removed from the product.
 #pragma once
-#include "../../rs-tfhe_amd/csrc/blind_rotate.hpp"
+#include "../../../rs-tfhe_amd/csrc/blind_rotate.hpp"
 
 namespace tfhe {
 

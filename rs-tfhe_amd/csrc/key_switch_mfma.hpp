@@ -30,7 +30,7 @@
 //     are the SAME digit position j of four consecutive coefficients: one ds_read_b128 and four
 //     (add, shift, and, shift) per fragment per step.
 // Bound: the matrix pipes and the clock they are allowed (operand-toggling limited: profiles/exp/ubench_mfma.hip).
-// 65,536 x 704 x 36,864 x 4 planes x 2 = 1.36e16 int8 ops per launch at SECURITY_128_BIT (a quarter of them
+// 65,536 x 704 x 36,864 x 4 planes x 2 = 1.36e13 int8 ops per launch at SECURITY_128_BIT (a quarter of them
 // against the zero k = 0 rows); the key planes cross L2 -> LDS once per workgroup (52 GB per launch).
 #pragma once
 #include <hip/hip_runtime.h>

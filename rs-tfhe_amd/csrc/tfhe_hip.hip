@@ -28,10 +28,10 @@
 #include "blind_rotate.hpp"
 #include "blind_rotate_wide.hpp"
 #if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)
-#include "../../profiles/exp/blind_rotate_l1.hpp"
+#include "../../profiles/exp/superseded/blind_rotate_l1.hpp"
 #endif
 #if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)
-#include "../../profiles/exp/blind_rotate_wide1.hpp"
+#include "../../profiles/exp/superseded/blind_rotate_wide1.hpp"
 #endif
 #include "key_switch.hpp"
 #include "key_switch_mfma.hpp"
@@ -311,7 +311,7 @@ int record_end(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_
 }
 
 typedef void (*br_kernel_t)(BlindRotateArgs);
-#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)  // the three-waves-per-SIMD l = 1 experiment (profiles/exp/blind_rotate_l1.hpp)
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)  // the three-waves-per-SIMD l = 1 experiment (profiles/exp/superseded/blind_rotate_l1.hpp)
 bool br_is_l1(const tfhe_hip_ctx *ctx) { return ctx->P.l == 1; }
 int br_waves(const tfhe_hip_ctx *ctx) { return br_is_l1(ctx) ? kL1Waves : kBrWaves; }
 #else
@@ -341,7 +341,7 @@ br_kernel_t br_pair_kernel(const tfhe_hip_ctx *ctx) {
 
 br_kernel_t br_single_kernel(const tfhe_hip_ctx *ctx) {
   const bool f = ctx->fast_round;
-#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)  // the superseded one-wave-per-row latency kernel (profiles/exp/blind_rotate_wide1.hpp)
+#if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_WIDE1)  // the superseded one-wave-per-row latency kernel (profiles/exp/superseded/blind_rotate_wide1.hpp)
   if (ctx->exp_wide1) switch (ctx->P.l) {
       case 1: return f ? k_blind_rotate_wide<1, true> : k_blind_rotate_wide<1, false>;
       case 2: return f ? k_blind_rotate_wide<2, true> : k_blind_rotate_wide<2, false>;
