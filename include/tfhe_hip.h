@@ -360,6 +360,9 @@ typedef struct tfhe_hip_combine_stats {
   uint64_t max_requests_per_launch; /* most calls taken by one leader at once                     */
   uint64_t lingers;                 /* leaders that waited for the previous launch's callers      */
   double linger_us;                 /* ... and for how long in all                                */
+  double pack_us;                   /* leaders' time, summed: packing operands into the arena     */
+  double gpu_us;                    /* ... copies in, kernels, copy out, the synchronise          */
+  double unpack_us;                 /* ... handing every caller its rows                          */
 } tfhe_hip_combine_stats;
 /* Counters since the last call; resets them. */
 int tfhe_hip_get_combine_stats(tfhe_hip_ctx *ctx, tfhe_hip_combine_stats *out);

@@ -59,7 +59,7 @@ class CombineStats(C.Structure):
 
     _fields_ = [("max_count", C.c_uint64), ("launches", C.c_uint64), ("requests", C.c_uint64),
                 ("ciphertexts", C.c_uint64), ("max_requests_per_launch", C.c_uint64), ("lingers", C.c_uint64),
-                ("linger_us", C.c_double)]
+                ("linger_us", C.c_double), ("pack_us", C.c_double), ("gpu_us", C.c_double), ("unpack_us", C.c_double)]
 
 
 _P = C.c_void_p

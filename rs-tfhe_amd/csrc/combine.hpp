@@ -33,15 +33,9 @@
 // are found by the caller before it queues, and a failure of the merged launch is copied into every request it carried
 // and filed under the calling thread's own error text.
 #pragma once
-#include <linux/futex.h>
-#include <sys/syscall.h>
-#include <unistd.h>
+#include "combine_queue.hpp"
 
-#include <chrono>
-#include <climits>
-#include <thread>
-
-struct CombReq {
+struct CombReq : combq::Node {
   KeyState *key = nullptr;
   int cls = 0;                    // CombClass
   int gate = TFHE_HIP_COPY;       // CB_GATES: the call's gate when `codes` is NULL
@@ -51,66 +45,22 @@ struct CombReq {
   const uint32_t *testvec = nullptr;  // CB_GATES: NULL = the key's own
   int per_ct = 0;
   uint32_t *out = nullptr;
-  size_t count = 0;
   int rc = TFHE_HIP_OK;
   std::string err;
-  // QUEUED until a leader takes it, DONE when its rows are in `out` (or rc / err say why not).  The owner's frame may
-  // go away the moment it reads DONE: a leader does not touch a request after storing that.
-  enum : uint32_t { QUEUED = 0, TAKEN = 1, DONE = 2 };
-  std::atomic<uint32_t> state{QUEUED};
-  CombReq *next = nullptr;  // the arrival list (newest first)
 };
 
-// No mutex on the callers' path: with hundreds of threads released at the same instant by one merged launch, a
-// condition variable's mutex is re-acquired by every one of them in turn (measured: a 256-thread team spent as long in
-// that queue as in the launch).  Arrivals push themselves onto a lock-free list, lanes are bits of one word, and
-// everybody who has to wait sleeps on ONE futex word (`epoch`) that is bumped whenever something completes or a lane
-// becomes free; woken threads look at their own request's state and go back to sleep if it is not their turn.
-struct Combiner {
-  static constexpr int kLanes = 4;  // most lanes a front end can have
+// The queue (combine_queue.hpp: arrival list, lane bits, the futex word, lingering, statistics) plus what is HIP's:
+// the lanes' private contexts and the bound on the calls that are merged.
+struct Combiner : combq::Queue {
   static constexpr size_t kBatchCap = 4096;  // ciphertexts per merged launch (bounds the pinned arenas)
-  int nlanes = 1;                   // lanes in use (see the note on lanes below)
-  struct Lane {
-    tfhe_hip_ctx *x = nullptr;  // created by its first leader
-    std::atomic<uint64_t> gen{0};  // leader rounds completed on this lane
-  };
-  Lane lane[kLanes];
-  std::atomic<CombReq *> arrivals_head{nullptr};
-  std::atomic<uint32_t> lanes_busy{0};  // bit i: lane i has a leader
-  std::atomic<uint32_t> epoch{0};       // the futex word
-  std::atomic<uint32_t> sleepers{0};    // threads in (or about to enter) futex_wait: nobody to wake, no system call
-  std::atomic<uint32_t> collecting{0};  // leaders between taking a lane and taking the arrival list: arrivals do not lead, they will be taken
-  std::atomic<size_t> max_count{0};  // calls of up to this many ciphertexts are merged; 0 = front end off
-  std::atomic<size_t> pending{0};    // ciphertexts queued or in flight (a pool picks its least loaded member by it)
-  std::atomic<uint64_t> arrivals{0};  // requests ever queued (the lingering leader watches it grow)
-  std::atomic<uint64_t> taken{0};     // requests ever taken by a leader
-  std::atomic<bool> profiling{false};  // what lanes created later start with
-  // the last leader round that completed: how many requests it carried, and when (steady_clock ns)
-  std::atomic<size_t> last_reqs{0};
-  std::atomic<int64_t> last_done_ns{0};
-  // lingering (see the header comment): only within linger_window of a round that carried several requests; ends when
-  // as many requests are waiting as that round carried (`want`), when nobody has arrived for linger_quiet + want / 4
-  // microseconds, or after linger_max + want microseconds (a team of hundreds of threads takes that long to come back
-  // through the scheduler; a launch that leaves without most of them makes them wait a whole launch: measured at 256
-  // threads, 41 k gates/s with a 10 us quiet gap, 65 k with 100 us -- profiles/exp/logs/r6b_front_end.log)
-  long linger_window_us = 1000, linger_quiet_us = 25, linger_max_us = 250;
-  // statistics (tfhe_hip_get_combine_stats); leaders only
-  std::mutex st_mu;
-  uint64_t st_launches = 0, st_requests = 0, st_cts = 0, st_max_requests = 0, st_lingers = 0;
-  double st_linger_us = 0;
+  tfhe_hip_ctx *lane_ctx[kLanes] = {};  // created by the lane's first leader
+  std::atomic<size_t> max_count{0};     // calls of up to this many ciphertexts are merged; 0 = front end off
+  std::atomic<bool> profiling{false};   // what lanes created later start with
 };
 
 namespace {
 
 enum CombClass { CB_GATES = 0, CB_MUX = 1, CB_MUX_NAIVE = 2 };
-
-inline void cpu_relax() {
-#if defined(__x86_64__) || defined(__i386__)
-  __builtin_ia32_pause();
-#else
-  std::this_thread::yield();
-#endif
-}
 
 // a lane's staging pair for one operand: pinned arena (packed by the leader) -> device buffer
 int comb_arena(tfhe_hip_ctx *x, PinBuf &pin, DevBuf &dev, size_t bytes) {
@@ -120,8 +70,9 @@ int comb_arena(tfhe_hip_ctx *x, PinBuf &pin, DevBuf &dev, size_t bytes) {
 }
 
 // One merged launch: requests of one key view and one operation class, in queue order.  x's device is current.
-int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> &g) {
+int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> &g, double (&phase_us)[3]) {
   KeyBind kb(x, key);
+  const auto t_begin = std::chrono::steady_clock::now();
   const CombReq &r0 = *g[0];
   const size_t w = (size_t)x->P.n + 1, wb = w * 4;
   size_t m = 0;
@@ -163,6 +114,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
       at += r->count;
     }
   }
+  const auto t_packed = std::chrono::steady_clock::now();
   HIPCHK(x, hipMemcpyAsync(x->h_a.p, x->p_a.p, m * wb, hipMemcpyHostToDevice, s));
   if (need_b) HIPCHK(x, hipMemcpyAsync(x->h_b.p, x->p_b.p, m * wb, hipMemcpyHostToDevice, s));
   if (need_c) HIPCHK(x, hipMemcpyAsync(x->h_c.p, x->p_c.p, m * wb, hipMemcpyHostToDevice, s));
@@ -188,6 +140,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
   }
   HIPCHK(x, hipMemcpyAsync(x->p_out.p, x->h_out.p, m * wb, hipMemcpyDeviceToHost, s));
   HIPCHK(x, hipStreamSynchronize(s));
+  const auto t_synced = std::chrono::steady_clock::now();
   {
     size_t at = 0;
     for (CombReq *r : g) {
@@ -195,11 +148,15 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
       at += r->count;
     }
   }
+  const auto t_end = std::chrono::steady_clock::now();
+  phase_us[0] += std::chrono::duration<double, std::micro>(t_packed - t_begin).count();
+  phase_us[1] += std::chrono::duration<double, std::micro>(t_synced - t_packed).count();
+  phase_us[2] += std::chrono::duration<double, std::micro>(t_end - t_synced).count();
   return TFHE_HIP_OK;
 }
 
 // the lane's private context: the base's parameters and dispatch, its own stream / scratch / staging
-int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, Combiner::Lane &L, std::string &why) {
+int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, int li, std::string &why) {
   tfhe_hip_ctx *x = nullptr;
   const int rc = tfhe_hip_ctx_create(&base->P, base->device, &x);
   if (rc != TFHE_HIP_OK) {
@@ -224,162 +181,65 @@ int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, Combiner::Lane &L, std::stri
   x->exp_wide1 = base->exp_wide1;
   x->fast_round = base->fast_round;
   x->profiling = C.profiling.load(std::memory_order_relaxed);
-  L.x = x;
+  C.lane_ctx[li] = x;
   return TFHE_HIP_OK;
 }
 
-// ---- waiting and waking: one futex word ---------------------------------------------------------------------------
-inline void comb_wait(Combiner &C, uint32_t seen) {
-  C.sleepers.fetch_add(1, std::memory_order_seq_cst);
-  if (C.epoch.load(std::memory_order_seq_cst) == seen)
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&C.epoch), FUTEX_WAIT_PRIVATE, seen, nullptr, nullptr, 0);
-  C.sleepers.fetch_sub(1, std::memory_order_seq_cst);
-}
-inline void comb_wake_all(Combiner &C) {
-  C.epoch.fetch_add(1, std::memory_order_seq_cst);
-  if (C.sleepers.load(std::memory_order_seq_cst))
-    (void)syscall(SYS_futex, reinterpret_cast<uint32_t *>(&C.epoch), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
-}
-inline int comb_try_lane(Combiner &C) {  // a free lane, now this thread's; -1: none
-  uint32_t busy = C.lanes_busy.load(std::memory_order_relaxed);
-  for (;;) {
-    int li = -1;
-    for (int i = 0; i < C.nlanes && li < 0; ++i)
-      if (!(busy & (1u << i))) li = i;
-    if (li < 0) return -1;
-    if (C.lanes_busy.compare_exchange_weak(busy, busy | (1u << li), std::memory_order_acquire, std::memory_order_relaxed)) return li;
-  }
-}
-inline void comb_release_lane(Combiner &C, int li) {
-  C.lane[li].gen.fetch_add(1, std::memory_order_release);
-  C.lanes_busy.fetch_and(~(1u << li), std::memory_order_release);
-  comb_wake_all(C);
-}
-inline int64_t comb_now_ns() {
-  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-// The calling thread holds lane `li`: it takes whatever has arrived, runs it, marks it done and releases the lane.
-void comb_lead(tfhe_hip_ctx *base, Combiner &C, int li) {
-  Combiner::Lane &L = C.lane[li];
-  C.collecting.fetch_add(1, std::memory_order_seq_cst);
-  // the callers of the round that has just completed are on their way back: give them a bounded moment
-  {
-    const size_t want = C.last_reqs.load(std::memory_order_relaxed);
-    const uint64_t taken0 = C.taken.load(std::memory_order_relaxed);
-    auto waiting = [&] { return (size_t)(C.arrivals.load(std::memory_order_relaxed) - taken0); };
-    const int64_t t0 = comb_now_ns();
-    if (want > 1 && waiting() < want && t0 - C.last_done_ns.load(std::memory_order_relaxed) < C.linger_window_us * 1000) {
-      int64_t last_growth = t0, now = t0;
-      size_t seen = waiting();
-      for (;;) {
-        cpu_relax();
-        now = comb_now_ns();
-        const size_t cur = waiting();
-        if (cur != seen) {
-          seen = cur;
-          last_growth = now;
-        }
-        if (cur >= want || now - last_growth > (C.linger_quiet_us * 4 + (long)want) * 250 || now - t0 > (C.linger_max_us + (long)want) * 1000) break;
-      }
-      std::lock_guard<std::mutex> lk(C.st_mu);
-      ++C.st_lingers;
-      C.st_linger_us += (double)(now - t0) * 1e-3;
-    }
-  }
-  // take the arrival list (newest first) and put it in arrival order
+// What the leader of lane `li` does with the requests it took: groups of (key view, class, key switch or not, own test
+// vector or not), each in arrival order and cut at kBatchCap ciphertexts, one merged launch per group.
+combq::Round comb_run_round(tfhe_hip_ctx *base, Combiner &C, int li, std::vector<combq::Node *> &nodes) {
+  combq::Round rd;
   std::vector<CombReq *> all;
-  for (CombReq *r = C.arrivals_head.exchange(nullptr, std::memory_order_acquire); r;) {
-    CombReq *nx = r->next;  // (read before anything can complete the request)
-    all.push_back(r);
-    r = nx;
+  all.reserve(nodes.size());
+  for (combq::Node *n : nodes) all.push_back(static_cast<CombReq *>(n));
+  DeviceGuard dg(base->device);
+  std::string why;
+  int rc = dg.err == hipSuccess ? TFHE_HIP_OK : TFHE_HIP_EHIP;
+  if (rc != TFHE_HIP_OK) why = std::string("hipSetDevice: ") + hipGetErrorString(dg.err);
+  if (rc == TFHE_HIP_OK && !C.lane_ctx[li]) rc = comb_make_lane(base, C, li, why);
+  if (rc != TFHE_HIP_OK) {
+    for (CombReq *r : all) {
+      r->rc = rc;
+      r->err = why;
+    }
+    return rd;
   }
-  std::reverse(all.begin(), all.end());
-  C.taken.fetch_add(all.size(), std::memory_order_relaxed);
-  for (CombReq *r : all) r->state.store(CombReq::TAKEN, std::memory_order_seq_cst);
-  C.collecting.fetch_sub(1, std::memory_order_seq_cst);
-  // a request that arrived after the list was taken may have seen `collecting` and gone to sleep expecting to be taken
-  if (C.arrivals_head.load(std::memory_order_seq_cst)) comb_wake_all(C);
-  size_t launches = 0, total = 0;
-  if (!all.empty()) {
-    DeviceGuard dg(base->device);
-    std::string why;
-    int rc = dg.err == hipSuccess ? TFHE_HIP_OK : TFHE_HIP_EHIP;
-    if (rc != TFHE_HIP_OK) why = std::string("hipSetDevice: ") + hipGetErrorString(dg.err);
-    if (rc == TFHE_HIP_OK && !L.x) rc = comb_make_lane(base, C, L, why);
-    if (rc != TFHE_HIP_OK) {
-      for (CombReq *r : all) {
-        r->rc = rc;
-        r->err = why;
-      }
-    } else {
-      // groups: (key view, class, key switch or not, own test vector or not), each in arrival order and cut at
-      // kBatchCap ciphertexts
-      std::vector<bool> placed(all.size(), false);
-      for (size_t i = 0; i < all.size(); ++i) {
-        if (placed[i]) continue;
-        const CombReq &h = *all[i];
-        std::vector<CombReq *> g;
-        size_t m = 0;
-        for (size_t j = i; j < all.size(); ++j) {
-          const CombReq &r = *all[j];
-          if (placed[j] || r.key != h.key || r.cls != h.cls || r.keyswitch != h.keyswitch || (r.testvec != nullptr) != (h.testvec != nullptr)) continue;
-          if (!g.empty() && m + r.count > Combiner::kBatchCap) break;  // the rest of this group: a launch of its own
-          placed[j] = true;
-          g.push_back(all[j]);
-          m += r.count;
-        }
-        const int grc = comb_run_group(L.x, h.key, g);
-        ++launches;
-        if (grc != TFHE_HIP_OK) {
-          const std::string text = err_text(L.x->id);
-          for (CombReq *r : g) {
-            r->rc = grc;
-            r->err = text;
-          }
-        }
+  tfhe_hip_ctx *x = C.lane_ctx[li];
+  double phase_us[3] = {0, 0, 0};
+  std::vector<bool> placed(all.size(), false);
+  for (size_t i = 0; i < all.size(); ++i) {
+    if (placed[i]) continue;
+    const CombReq &h = *all[i];
+    std::vector<CombReq *> g;
+    size_t m = 0;
+    for (size_t j = i; j < all.size(); ++j) {
+      const CombReq &r = *all[j];
+      if (placed[j] || r.key != h.key || r.cls != h.cls || r.keyswitch != h.keyswitch || (r.testvec != nullptr) != (h.testvec != nullptr)) continue;
+      if (!g.empty() && m + r.count > Combiner::kBatchCap) break;  // the rest of this group: a launch of its own
+      placed[j] = true;
+      g.push_back(all[j]);
+      m += r.count;
+    }
+    const int grc = comb_run_group(x, h.key, g, phase_us);
+    ++rd.launches;
+    if (grc != TFHE_HIP_OK) {
+      const std::string text = err_text(x->id);
+      for (CombReq *r : g) {
+        r->rc = grc;
+        r->err = text;
       }
     }
-    for (CombReq *r : all) total += r->count;
-    C.pending.fetch_sub(total, std::memory_order_relaxed);
-    C.last_reqs.store(all.size(), std::memory_order_relaxed);
-    C.last_done_ns.store(comb_now_ns(), std::memory_order_relaxed);
-    {
-      std::lock_guard<std::mutex> lk(C.st_mu);
-      C.st_launches += launches;
-      C.st_requests += all.size();
-      C.st_cts += total;
-      if (all.size() > C.st_max_requests) C.st_max_requests = all.size();
-    }
-    for (CombReq *r : all) r->state.store(CombReq::DONE, std::memory_order_release);  // (r may be gone after this)
   }
-  comb_release_lane(C, li);
+  rd.pack_us = phase_us[0];
+  rd.gpu_us = phase_us[1];
+  rd.unpack_us = phase_us[2];
+  return rd;
 }
 
-// queue the request, lead when a lane is free, return when the request has been served
+// queue the request, lead when the lane is free, return when the request has been served
 int comb_submit(tfhe_hip_ctx *base, CombReq &r) {
   Combiner &C = *base->comb;
-  C.pending.fetch_add(r.count, std::memory_order_relaxed);
-  {
-    CombReq *h = C.arrivals_head.load(std::memory_order_relaxed);
-    do r.next = h;
-    while (!C.arrivals_head.compare_exchange_weak(h, &r, std::memory_order_release, std::memory_order_relaxed));
-  }
-  C.arrivals.fetch_add(1, std::memory_order_relaxed);
-  for (;;) {
-    const uint32_t e = C.epoch.load(std::memory_order_seq_cst);  // (before the checks: a wake-up in between is not lost)
-    const uint32_t st = r.state.load(std::memory_order_acquire);
-    if (st == CombReq::DONE) break;
-    if (st == CombReq::QUEUED && C.collecting.load(std::memory_order_seq_cst) == 0) {
-      const int li = comb_try_lane(C);
-      if (li >= 0) {
-        if (r.state.load(std::memory_order_seq_cst) == CombReq::QUEUED) comb_lead(base, C, li);  // takes this request too
-        else comb_release_lane(C, li);  // another leader took it meanwhile
-        continue;
-      }
-    }
-    comb_wait(C, e);
-  }
+  C.submit(r, [&](std::vector<combq::Node *> &nodes, int li) { return comb_run_round(base, C, li, nodes); });
   if (r.rc != TFHE_HIP_OK) err_slot(base->id) = r.err;
   return r.rc;
 }
@@ -393,16 +253,7 @@ inline bool comb_takes(const tfhe_hip_ctx *ctx, size_t count) {
 // Whatever the lanes had in flight when this is called has completed when it returns (a key is about to change or go:
 // nothing may still read it).  Calls under the key that is changing are the caller's to keep away, as for any call.
 void comb_quiesce(tfhe_hip_ctx *base) {
-  Combiner *C = base->comb;
-  if (!C) return;
-  for (int i = 0; i < Combiner::kLanes; ++i) {
-    const uint64_t g = C->lane[i].gen.load(std::memory_order_acquire);
-    for (;;) {
-      const uint32_t e = C->epoch.load(std::memory_order_seq_cst);
-      if (!(C->lanes_busy.load(std::memory_order_acquire) & (1u << i)) || C->lane[i].gen.load(std::memory_order_acquire) != g) break;
-      comb_wait(*C, e);
-    }
-  }
+  if (base->comb) base->comb->quiesce();
 }
 
 // every lane idle, and held idle while f runs (f must not submit)
@@ -410,24 +261,15 @@ template <class F>
 void comb_with_idle_lanes(tfhe_hip_ctx *base, F &&f) {
   Combiner *C = base->comb;
   if (!C) return;
-  const uint32_t all = (1u << Combiner::kLanes) - 1;
-  for (;;) {  // take every lane bit at once
-    const uint32_t e = C->epoch.load(std::memory_order_seq_cst);
-    uint32_t none = 0;
-    if (C->lanes_busy.compare_exchange_strong(none, all, std::memory_order_acquire, std::memory_order_relaxed)) break;
-    comb_wait(*C, e);
-  }
-  f(*C);
-  C->lanes_busy.store(0, std::memory_order_release);
-  comb_wake_all(*C);
+  C->with_idle_lanes([&] { f(*C); });
 }
 
 void comb_destroy(tfhe_hip_ctx *base) {
   Combiner *C = base->comb;
   if (!C) return;
-  comb_quiesce(base);
+  C->quiesce();
   for (int i = 0; i < Combiner::kLanes; ++i)
-    if (C->lane[i].x) tfhe_hip_ctx_destroy(C->lane[i].x);
+    if (C->lane_ctx[i]) tfhe_hip_ctx_destroy(C->lane_ctx[i]);
   base->comb = nullptr;
   delete C;
 }

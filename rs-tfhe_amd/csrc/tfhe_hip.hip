@@ -2075,8 +2075,8 @@ int tfhe_hip_set_profiling(tfhe_hip_ctx *ctx, int enabled) {
   ctx->profiling = enabled != 0;
   comb_with_idle_lanes(ctx, [&](Combiner &C) {  // the front end's lanes record their launches too
     C.profiling = enabled != 0;
-    for (auto &L : C.lane)
-      if (L.x) L.x->profiling = enabled != 0;
+    for (tfhe_hip_ctx *x : C.lane_ctx)
+      if (x) x->profiling = enabled != 0;
   });
   return TFHE_HIP_OK;
 }
@@ -2104,12 +2104,12 @@ int tfhe_hip_get_kernel_times(tfhe_hip_ctx *ctx, tfhe_hip_kernel_times *out) {
   ctx->bootstraps = 0;
   int lane_rc = TFHE_HIP_OK;  // merged launches of small calls ran on the front end's lanes
   comb_with_idle_lanes(ctx, [&](Combiner &C) {
-    for (auto &L : C.lane) {
-      if (!L.x) continue;
-      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(L.x->ev_br, out->blind_rotate_ms, out->blind_rotate_launches);
-      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(L.x->ev_ks, out->key_switch_ms, out->key_switch_launches);
-      out->bootstraps += L.x->bootstraps;
-      L.x->bootstraps = 0;
+    for (tfhe_hip_ctx *x : C.lane_ctx) {
+      if (!x) continue;
+      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(x->ev_br, out->blind_rotate_ms, out->blind_rotate_launches);
+      if (lane_rc == TFHE_HIP_OK) lane_rc = drain(x->ev_ks, out->key_switch_ms, out->key_switch_launches);
+      out->bootstraps += x->bootstraps;
+      x->bootstraps = 0;
     }
   });
   return lane_rc;
@@ -2207,12 +2207,15 @@ int tfhe_hip_get_combine_stats(tfhe_hip_ctx *ctx, tfhe_hip_combine_stats *out) {
   out->max_count = C->max_count.load(std::memory_order_relaxed);
   out->launches = C->st_launches;
   out->requests = C->st_requests;
-  out->ciphertexts = C->st_cts;
+  out->ciphertexts = C->st_units;
   out->max_requests_per_launch = C->st_max_requests;
   out->lingers = C->st_lingers;
   out->linger_us = C->st_linger_us;
-  C->st_launches = C->st_requests = C->st_cts = C->st_max_requests = C->st_lingers = 0;
-  C->st_linger_us = 0;
+  out->pack_us = C->st_pack_us;
+  out->gpu_us = C->st_gpu_us;
+  out->unpack_us = C->st_unpack_us;
+  C->st_launches = C->st_requests = C->st_units = C->st_max_requests = C->st_lingers = 0;
+  C->st_linger_us = C->st_pack_us = C->st_gpu_us = C->st_unpack_us = 0;
   return TFHE_HIP_OK;
 }
 

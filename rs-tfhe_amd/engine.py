@@ -544,7 +544,7 @@ class Engine:
         """Counters of the combining front end since the last call (`tfhe_hip_get_combine_stats`)."""
         st = _capi.CombineStats()
         self._chk(self._lib.tfhe_hip_get_combine_stats(self._ctx, C.byref(st)))
-        return {k: (float(getattr(st, k)) if k == "linger_us" else int(getattr(st, k))) for k, _ in st._fields_}
+        return {k: (float(getattr(st, k)) if k.endswith("_us") else int(getattr(st, k))) for k, _ in st._fields_}
 
     @property
     def rounding_mode(self) -> str:

@@ -24,6 +24,18 @@ def test_device_fft_algebra_on_host():
     assert r.returncode == 0 and "all checks passed" in r.stdout
 
 
+def test_front_end_queue_under_thread_sanitizer():
+    """rs-tfhe_amd/csrc/combine_queue.hpp (lock-free arrival list, lane bits, one futex word, lingering leader) compiled
+    with -fsanitize=thread and driven by up to 64 threads with a stand-in for the launch: every request served exactly
+    once with its own result, no report from ThreadSanitizer, quiesce / with_idle_lanes beside the traffic."""
+    subprocess.check_call(["make", "-C", CPP, "build/test_combine_queue"])
+    r = subprocess.run([os.path.join(CPP, "build", "test_combine_queue")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1 second_deadlock_stack=1"))
+    print(r.stdout[-3000:], r.stderr[-6000:])
+    assert r.returncode == 0 and "all queue checks passed" in r.stdout
+    assert "ThreadSanitizer" not in r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_mirror_runs_on_gpu():
     exe = os.path.join(CPP, "build", "test_mirror")
