@@ -13,7 +13,7 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
 if [ -n "$COLLECT_PROG" ]; then TRACE_CMD="$COLLECT_PROG"; PMC_CMD="$COLLECT_PROG"
-else TRACE_CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"; PMC_CMD="bench.py --steps 1 --warmup 0 --no-cpu-baseline $*"; fi
+else TRACE_CMD="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $*"; PMC_CMD="bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs $*"; fi
 rocprofv3 --kernel-trace --stats -d "$O/trace" -- python3 $TRACE_CMD > "$O/trace.log" 2>&1
 # the bench line of THIS run (HIP-event launch times of the very launches the trace holds) beside the trace summary
 grep '^{"metric"' "$O/trace.log" > "$R/gpurun_out/${tag}_trace_bench.json" || true
