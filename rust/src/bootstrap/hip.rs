@@ -103,7 +103,7 @@ struct KeyView { addr: usize, fp: u64, view: *mut TfheHipPool, last_use: u64, us
 
 /// Owns the C pool (one context per device) and the key views on it.
 pub struct HipEngine { pool: *mut TfheHipPool, views: Mutex<(Vec<KeyView>, u64)> }
-unsafe impl Send for HipEngine {}   // the library serialises calls per context; `views` is behind its Mutex
+unsafe impl Send for HipEngine {}   // the library merges concurrent small calls into shared launches and serialises the rest per context; `views` is behind its Mutex
 unsafe impl Sync for HipEngine {}
 
 impl HipEngine {

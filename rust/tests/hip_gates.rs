@@ -120,6 +120,38 @@ fn test_hip_bootstrap_without_key_switch() {
     }
 }
 
+/// `Bootstrap: Send + Sync` (bootstrap/mod.rs:23): a Rayon team calling ONE strategy -- the user-side counterpart of
+/// parallel/rayon_impl.rs:40-47.  The library merges the one-ciphertext calls that are in flight together into shared
+/// launches (rs-tfhe_amd/csrc/combine.hpp); every result must still be the CPU strategy's, word for word, in input order,
+/// and the team must beat the same calls made one after the other by a wide margin.
+#[test]
+fn test_a_rayon_team_on_one_strategy() {
+    use rayon::prelude::*;
+    let mut rng = rand::thread_rng();
+    let (key, cloud_key) = keys();
+    let gates = Gates::with_bootstrap(Box::new(HipBootstrap::new()));
+    let cpu = Gates::with_bootstrap(Box::new(VanillaBootstrap::new()));
+    let plains: Vec<(bool, bool)> = (0..512).map(|_| (rng.gen::<bool>(), rng.gen::<bool>())).collect();
+    let pairs: Vec<(Ciphertext, Ciphertext)> = plains.iter().map(|&(a, b)| (enc(a, &key), enc(b, &key))).collect();
+    let t0 = std::time::Instant::now();
+    let one_by_one: Vec<Ciphertext> = pairs.iter().take(32).map(|(a, b)| gates.nand(a, b, &cloud_key)).collect();
+    let serial = 32.0 / t0.elapsed().as_secs_f64();
+    let t1 = std::time::Instant::now();
+    let team: Vec<Ciphertext> = pairs.par_iter().map(|(a, b)| gates.nand(a, b, &cloud_key)).collect();
+    let together = 512.0 / t1.elapsed().as_secs_f64();
+    for (i, (out, &(a, b))) in team.iter().zip(plains.iter()).enumerate() {
+        assert_eq!(out.decrypt_bool(&key.key_lv0), !(a & b), "gate {}", i);
+    }
+    for (out, single) in team.iter().zip(one_by_one.iter()) {
+        assert_eq!(out.p, single.p); // merged or alone: the same bits
+    }
+    for (out, (a, b)) in team.iter().zip(pairs.iter()).take(16) {
+        assert_eq!(out.p, cpu.nand(a, b, &cloud_key).p);
+    }
+    println!("one by one {:.0} gates/s, a Rayon team {:.0} gates/s", serial, together);
+    assert!(rayon::current_num_threads() < 4 || together > 2.0 * serial);
+}
+
 /// vanilla.rs:127-131
 #[test]
 fn test_bootstrap_trait() {

@@ -271,6 +271,7 @@ RUST_STD_METHODS = {  # methods of std types the binding calls (slices, iterator
     "enumerate", "expect", "extend_from_slice", "fill_bytes", "filter", "find", "for_each", "get_or_init", "is_null", "is_power_of_two",
     "iter", "iter_mut", "len", "lock", "map", "map_or", "min_by_key", "parse", "pop", "position", "push", "remove", "split", "to_str",
     "to_string_lossy", "trailing_zeros", "trim", "unwrap", "unwrap_or", "with", "wrapping_mul", "zip", "to_bits", "get", "is_empty",
+    "par_iter", "take", "elapsed", "as_secs_f64",  # (rayon's ParallelIterator, Iterator::take, Instant / Duration)
 }
 
 
