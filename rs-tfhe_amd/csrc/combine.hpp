@@ -56,6 +56,7 @@ struct Combiner : combq::Queue {
   tfhe_hip_ctx *lane_ctx[kLanes] = {};  // created by the lane's first leader
   std::atomic<size_t> max_count{0};     // calls of up to this many ciphertexts are merged; 0 = front end off
   std::atomic<bool> profiling{false};   // what lanes created later start with
+  bool zero_copy_in = false;            // gate groups: the kernels read the pinned arena in place instead of a copy of it
 };
 
 namespace {
@@ -70,7 +71,7 @@ int comb_arena(tfhe_hip_ctx *x, PinBuf &pin, DevBuf &dev, size_t bytes) {
 }
 
 // One merged launch: requests of one key view and one operation class, in queue order.  x's device is current.
-int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> &g, double (&phase_us)[3]) {
+int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> &g, double (&phase_us)[3], bool zero_copy_in) {
   KeyBind kb(x, key);
   const auto t_begin = std::chrono::steady_clock::now();
   const CombReq &r0 = *g[0];
@@ -115,12 +116,23 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
     }
   }
   const auto t_packed = std::chrono::steady_clock::now();
-  HIPCHK(x, hipMemcpyAsync(x->h_a.p, x->p_a.p, m * wb, hipMemcpyHostToDevice, s));
-  if (need_b) HIPCHK(x, hipMemcpyAsync(x->h_b.p, x->p_b.p, m * wb, hipMemcpyHostToDevice, s));
-  if (need_c) HIPCHK(x, hipMemcpyAsync(x->h_c.p, x->p_c.p, m * wb, hipMemcpyHostToDevice, s));
-  if (has_tv) HIPCHK(x, hipMemcpyAsync(x->h_tv.p, x->p_tv.p, m * (size_t)2 * kN * 4, hipMemcpyHostToDevice, s));
-  if (!mux && !uniform) HIPCHK(x, hipMemcpyAsync(x->h_idx.p, x->p_idx.p, m, hipMemcpyHostToDevice, s));
+  // gate groups read each operand row once, in the blind rotation's prologue: with zero_copy_in the kernel takes the
+  // pinned arena as it is (no copy to wait for ahead of the launch); mux reads its operands in three launches: copied
+  const bool zc = zero_copy_in && !mux;
   const uint32_t *da = (const uint32_t *)x->h_a.p, *db = need_b ? (const uint32_t *)x->h_b.p : nullptr;
+  const uint32_t *dtv0 = has_tv ? (const uint32_t *)x->h_tv.p : nullptr;
+  if (zc) {
+    da = pinned_view((const uint32_t *)x->p_a.p, m * wb);
+    if (need_b) db = pinned_view((const uint32_t *)x->p_b.p, m * wb);
+    if (has_tv) dtv0 = pinned_view((const uint32_t *)x->p_tv.p, m * (size_t)2 * kN * 4);
+    if (!da || (need_b && !db) || (has_tv && !dtv0)) return fail(x, TFHE_HIP_EHIP, "merged-call arena is not device-addressable");
+  } else {
+    HIPCHK(x, hipMemcpyAsync(x->h_a.p, x->p_a.p, m * wb, hipMemcpyHostToDevice, s));
+    if (need_b) HIPCHK(x, hipMemcpyAsync(x->h_b.p, x->p_b.p, m * wb, hipMemcpyHostToDevice, s));
+    if (need_c) HIPCHK(x, hipMemcpyAsync(x->h_c.p, x->p_c.p, m * wb, hipMemcpyHostToDevice, s));
+    if (has_tv) HIPCHK(x, hipMemcpyAsync(x->h_tv.p, x->p_tv.p, m * (size_t)2 * kN * 4, hipMemcpyHostToDevice, s));
+  }
+  if (!mux && !uniform) HIPCHK(x, hipMemcpyAsync(x->h_idx.p, x->p_idx.p, m, hipMemcpyHostToDevice, s));
   uint32_t *dout = (uint32_t *)x->h_out.p;
   if (mux) {
     CHK(mux_dev(x, r0.cls == CB_MUX_NAIVE, da, db, (const uint32_t *)x->h_c.p, dout, m, s));
@@ -128,7 +140,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
     GatePrep gp{1u, need_b ? 1u : 0u, 0u};  // mixed: placeholders, the kernel reads the codes (cb != 0 keeps in_b attached)
     if (uniform) gate_prep(gate0, gp);
     const uint8_t *dcodes = uniform ? nullptr : (const uint8_t *)x->h_idx.p;
-    const uint32_t *dtv = has_tv ? (const uint32_t *)x->h_tv.p : nullptr;
+    const uint32_t *dtv = dtv0;
     if (r0.keyswitch) {
       CHK(claim_scratch(x, s));
       CHK(ensure(x, x->lv1, lv1_rows(m) * (size_t)(kN + 1) * 4));
@@ -181,6 +193,16 @@ int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, int li, std::string &why) {
   x->exp_wide1 = base->exp_wide1;
   x->fast_round = base->fast_round;
   x->profiling = C.profiling.load(std::memory_order_relaxed);
+  // arenas for a full round of the default bound up front (a, b, out: < 1 MB each): the first calls of a team do not
+  // pay for pinned allocations, and a growing team does not re-allocate them
+  {
+    const size_t rows = C.max_count.load(std::memory_order_relaxed) ? C.max_count.load(std::memory_order_relaxed) : 1;
+    const size_t bytes = rows * ((size_t)x->P.n + 1) * 4;
+    (void)comb_arena(x, x->p_a, x->h_a, bytes);
+    (void)comb_arena(x, x->p_b, x->h_b, bytes);
+    (void)comb_arena(x, x->p_out, x->h_out, bytes);
+    (void)ensure(x, x->lv1, lv1_rows(rows) * (size_t)(kN + 1) * 4);
+  }
   C.lane_ctx[li] = x;
   return TFHE_HIP_OK;
 }
@@ -220,7 +242,7 @@ combq::Round comb_run_round(tfhe_hip_ctx *base, Combiner &C, int li, std::vector
       g.push_back(all[j]);
       m += r.count;
     }
-    const int grc = comb_run_group(x, h.key, g, phase_us);
+    const int grc = comb_run_group(x, h.key, g, phase_us, C.zero_copy_in);
     ++rd.launches;
     if (grc != TFHE_HIP_OK) {
       const std::string text = err_text(x->id);
@@ -262,6 +284,18 @@ void comb_with_idle_lanes(tfhe_hip_ctx *base, F &&f) {
   Combiner *C = base->comb;
   if (!C) return;
   C->with_idle_lanes([&] { f(*C); });
+}
+
+// A key has just become current on `base` (its device is current): have the first lane ready, so that a caller's first
+// small call does not pay for a context and its arenas (6 ms measured; a failure here is not one -- the first leader
+// tries again and reports it).
+void comb_prepare(tfhe_hip_ctx *base) {
+  Combiner *C = base->comb;
+  if (!C || base->is_lane || C->max_count.load(std::memory_order_relaxed) == 0) return;
+  C->with_idle_lanes([&] {
+    std::string why;
+    if (!C->lane_ctx[0]) (void)comb_make_lane(base, *C, 0, why);
+  });
 }
 
 void comb_destroy(tfhe_hip_ctx *base) {

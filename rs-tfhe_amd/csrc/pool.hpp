@@ -99,6 +99,7 @@ int clone_key(tfhe_hip_ctx *dst, tfhe_hip_ctx *src) {
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = from->offset;
   ctx->K->key_loaded = true;
+  comb_prepare(ctx);
   return TFHE_HIP_OK;
 }
 
@@ -224,6 +225,7 @@ int finish_replica(tfhe_hip_ctx *member, uint32_t offset) {
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = offset;
   ctx->K->key_loaded = true;
+  comb_prepare(ctx);
   return TFHE_HIP_OK;
 }
 

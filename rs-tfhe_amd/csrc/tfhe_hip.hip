@@ -1230,6 +1230,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   ctx->comb->max_count = combine_max;
 #ifdef TFHE_EXPERIMENT
   if (const char *env = getenv("TFHE_HIP_COMBINE_LANES")) ctx->comb->nlanes = std::max(1, std::min((int)Combiner::kLanes, atoi(env)));
+  if (const char *env = getenv("TFHE_HIP_COMBINE_ZEROCOPY")) ctx->comb->zero_copy_in = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_LINGER_WINDOW_US")) ctx->comb->linger_window_us = atol(env);
   if (const char *env = getenv("TFHE_HIP_LINGER_QUIET_US")) ctx->comb->linger_quiet_us = atol(env);
   if (const char *env = getenv("TFHE_HIP_LINGER_MAX_US")) ctx->comb->linger_max_us = atol(env);
@@ -1375,6 +1376,7 @@ int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = decomp_offset;
   ctx->K->key_loaded = true;
+  comb_prepare(ctx);
   return TFHE_HIP_OK;
 }
 
@@ -1441,6 +1443,7 @@ int gen_cloud_key_locked(tfhe_hip_ctx *ctx, const uint32_t *key_lv0, const uint3
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = off;
   ctx->K->key_loaded = true;
+  comb_prepare(ctx);
   return TFHE_HIP_OK;
 }
 
@@ -1563,6 +1566,7 @@ int tfhe_hip_adopt_cloud_key(tfhe_hip_ctx *ctx, uint32_t decomp_offset) {
   CHK(build_ksk_planes(ctx));
   ctx->K->offset = decomp_offset;
   ctx->K->key_loaded = true;
+  comb_prepare(ctx);
   ctx->K->reenc_loaded = false;
   return TFHE_HIP_OK;
 }
