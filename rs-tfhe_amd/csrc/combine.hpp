@@ -57,6 +57,7 @@ struct Combiner : combq::Queue {
   std::atomic<size_t> max_count{0};     // calls of up to this many ciphertexts are merged; 0 = front end off
   std::atomic<bool> profiling{false};   // what lanes created later start with
   bool zero_copy_in = false;            // gate groups: the kernels read the pinned arena in place instead of a copy of it
+  bool lane_high_priority = false;      // the lanes' streams are created at the device's highest stream priority
 };
 
 namespace {
@@ -178,6 +179,20 @@ int comb_make_lane(tfhe_hip_ctx *base, Combiner &C, int li, std::string &why) {
   x->is_lane = true;
   delete x->comb;  // (a lane has no front end of its own)
   x->comb = nullptr;
+  if (C.lane_high_priority) {
+    // Small calls are the latency-sensitive ones: their launches go to a stream of the highest priority the device has,
+    // so that the command processor dispatches their few workgroups ahead of a bulk launch's thousands when both are
+    // pending (a 65,536-ciphertext batch on the context's own stream holds every CU for 330 ms).
+    int least = 0, greatest = 0;
+    hipStream_t hs = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least &&
+        hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, greatest) == hipSuccess) {
+      (void)hipStreamDestroy(x->stream);
+      x->stream = hs;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
   x->br_force = base->br_force;
   x->ks_force = base->ks_force;
   x->wide_max = base->wide_max;

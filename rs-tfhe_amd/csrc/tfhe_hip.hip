@@ -1231,6 +1231,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
 #ifdef TFHE_EXPERIMENT
   if (const char *env = getenv("TFHE_HIP_COMBINE_LANES")) ctx->comb->nlanes = std::max(1, std::min((int)Combiner::kLanes, atoi(env)));
   if (const char *env = getenv("TFHE_HIP_COMBINE_ZEROCOPY")) ctx->comb->zero_copy_in = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_LANE_PRIORITY")) ctx->comb->lane_high_priority = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_LINGER_WINDOW_US")) ctx->comb->linger_window_us = atol(env);
   if (const char *env = getenv("TFHE_HIP_LINGER_QUIET_US")) ctx->comb->linger_quiet_us = atol(env);
   if (const char *env = getenv("TFHE_HIP_LINGER_MAX_US")) ctx->comb->linger_max_us = atol(env);
