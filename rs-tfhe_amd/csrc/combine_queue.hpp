@@ -71,7 +71,7 @@ struct Queue {
   // as that (`want`), when nobody has arrived for linger_quiet + want / 4 microseconds, or after linger_max + want
   // microseconds (a team of hundreds of threads takes that long to come back through the scheduler; a launch that leaves
   // without most of them makes them wait a whole launch).
-  long linger_window_us = 1000, linger_quiet_us = 25, linger_max_us = 250;
+  long linger_window_us = 1000, linger_quiet_us = 50, linger_max_us = 250;
   // statistics; leaders only
   std::mutex st_mu;
   uint64_t st_launches = 0, st_requests = 0, st_units = 0, st_max_requests = 0, st_lingers = 0;
