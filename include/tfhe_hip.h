@@ -487,7 +487,10 @@ int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *pool, int member, double *bsk,
 
 /* The batched hot path over all members, HOST pointers: same arguments and semantics as the single-context host
  * entry points of the same name (gates.rs:352-547; gates.rs:157-199; bootstrap/{vanilla,lut}.rs; trgsw.rs:289-305;
- * tlwe.rs:129-214).  One host thread per shard; results land in the caller's output slice in input order. */
+ * tlwe.rs:129-214).  One host thread per shard; results land in the caller's output slice in input order.
+ * Small calls (gate / gates_mixed[_nks] / bootstrap / mux of at most the combining bound, see tfhe_hip_set_combining)
+ * made by concurrent threads do not queue on the pool: each goes to the member (one per distinct device) with the least
+ * work queued and shares launches there with the other threads' calls. */
 int tfhe_hip_pool_batch_gate(tfhe_hip_pool *pool, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,
                              size_t count);
 int tfhe_hip_pool_batch_gates_mixed(tfhe_hip_pool *pool, const uint8_t *gates, const uint32_t *a, const uint32_t *b,
