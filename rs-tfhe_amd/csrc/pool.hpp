@@ -924,6 +924,12 @@ int tfhe_hip_pool_batch_tlwe_lincomb(tfhe_hip_pool *p, uint32_t ca, const uint32
 int tfhe_hip_pool_batch_lincomb_bootstrap(tfhe_hip_pool *p, uint32_t ca, const uint32_t *a, uint32_t cb,
                                           const uint32_t *b, uint32_t cconst, const uint32_t *testvec, int per_ct,
                                           int keyswitch, uint32_t *out, size_t count) {
+  if (pool_small(p, count)) {
+    if (!a || !out || (cb && !b)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) {
+      return tfhe_hip_batch_lincomb_bootstrap(c, ca, a, cb, b, cconst, testvec, per_ct, keyswitch, out, count);
+    });
+  }
   POOL_ENTER(p);
   if (count && (!a || !out || (cb && !b))) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;

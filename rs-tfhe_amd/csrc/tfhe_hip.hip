@@ -1840,6 +1840,19 @@ int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint3
                                      const uint32_t *b, uint32_t cconst, const uint32_t *testvec,
                                      int per_ct, int keyswitch, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count) && a && out && (!cb || b)) {
+    // small call: the linear combination (wrapping u32 arithmetic, the words k_tlwe_lincomb / the kernels' prologue
+    // compute) is formed here by the caller, and the bootstrap of it joins the merged launches as a plain COPY
+    const size_t w = (size_t)(ctx->parent ? ctx->parent : ctx)->P.n + 1;
+    std::vector<uint32_t> prep(count * w);
+    for (size_t i = 0; i < count * w; ++i) {
+      uint32_t v = ca * a[i];
+      if (cb) v += cb * b[i];
+      if (i % w == w - 1) v += cconst;
+      prep[i] = v;
+    }
+    return comb_gate_call(ctx, TFHE_HIP_COPY, nullptr, keyswitch != 0, prep.data(), nullptr, testvec, per_ct, out, count);
+  }
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;

@@ -138,11 +138,11 @@ def test_every_kind_of_small_call_at_once_under_two_keys(O, eng128, keys128):
     v2.load_cloud_key(_cloud_key(ck2))
     rng = np.random.default_rng(604)
     jobs = []
-    for t in range(24):
+    for t in range(27):
         eng, s, k = (eng128, sk, ck) if t % 2 == 0 else (v2, sk2, ck2)
         n = int(rng.integers(1, 9))
         a, b, c = (s.encrypt_bool(rng.integers(0, 2, n).astype(bool), 7000 + 3 * t + j) for j in range(3))
-        kind = t % 8
+        kind = t % 9
         if kind == 0:
             jobs.append((lambda e=eng, a=a, b=b: e.batch_gate(O.GATE_XOR, a, b), lambda k=k, a=a, b=b: O.batch_gate(k, O.GATE_XOR, a, b)))
         elif kind == 1:
@@ -162,8 +162,14 @@ def test_every_kind_of_small_call_at_once_under_two_keys(O, eng128, keys128):
                          lambda k=k, a=a, tv=tv: O.batch_bootstrap(k, a, testvec=tv, keyswitch=False)))
         elif kind == 6:
             jobs.append((lambda e=eng, a=a, b=b, c=c: e.batch_mux(a, b, c, naive=False), lambda k=k, a=a, b=b, c=c: O.batch_mux(k, a, b, c, naive=False)))
-        else:
+        elif kind == 7:
             jobs.append((lambda e=eng, a=a, b=b, c=c: e.batch_mux(a, b, c, naive=True), lambda k=k, a=a, b=b, c=c: O.batch_mux(k, a, b, c, naive=True)))
+        else:  # a linear combination bootstrapped through a table (tfhe_hip_batch_lincomb_bootstrap: formed by the caller, merged as COPY)
+            tv = rng.integers(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
+            prep = (np.uint32(3) * a + np.uint32(0xFFFFFFFE) * b).astype(np.uint32)
+            prep[:, -1] += np.uint32(0x10000000)
+            jobs.append((lambda e=eng, a=a, b=b, tv=tv: e.batch_lincomb_bootstrap(3, a, 0xFFFFFFFE, b, 0x10000000, testvec=tv),
+                         lambda k=k, prep=prep, tv=tv: O.batch_bootstrap(k, prep, testvec=tv)))
     results, errors = [None] * len(jobs), []
 
     def work(i):
