@@ -62,12 +62,24 @@ struct Combiner : combq::Queue {
 
 namespace {
 
+bool g_comb_force_heap = false;  // (experiment builds, TFHE_HIP_COMBINE_HEAP: take the no-pinned-memory path of the lanes' arenas)
+
 enum CombClass { CB_GATES = 0, CB_MUX = 1, CB_MUX_NAIVE = 2 };
 
-// a lane's staging pair for one operand: pinned arena (packed by the leader) -> device buffer
+// a lane's staging pair for one operand: host arena (packed by the leader; pinned, or ordinary memory where pinned memory
+// is not to be had -- the copies work from either, only slower) -> device buffer
 int comb_arena(tfhe_hip_ctx *x, PinBuf &pin, DevBuf &dev, size_t bytes) {
   CHK(ensure(x, dev, bytes));
-  if (ensure_pinned(x, pin, bytes) != TFHE_HIP_OK) return fail(x, TFHE_HIP_ENOMEM, "hipHostMalloc: merged-call arena");
+  if (bytes <= pin.cap) return TFHE_HIP_OK;
+  if (!pin.heap && !g_comb_force_heap && ensure_pinned(x, pin, bytes) == TFHE_HIP_OK) return TFHE_HIP_OK;
+  if (pin.p && pin.heap) free(pin.p);
+  pin.p = nullptr;
+  pin.cap = 0;
+  const size_t want = bytes + bytes / 4;
+  pin.p = aligned_alloc(4096, (want + 4095) & ~(size_t)4095);
+  if (!pin.p) return fail(x, TFHE_HIP_ENOMEM, "merged-call arena: out of host memory");
+  pin.cap = want;
+  pin.heap = true;
   return TFHE_HIP_OK;
 }
 
@@ -119,7 +131,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
   const auto t_packed = std::chrono::steady_clock::now();
   // gate groups read each operand row once, in the blind rotation's prologue: with zero_copy_in the kernel takes the
   // pinned arena as it is (no copy to wait for ahead of the launch); mux reads its operands in three launches: copied
-  const bool zc = zero_copy_in && !mux;
+  const bool zc = zero_copy_in && !mux && !x->p_a.heap && !x->p_b.heap && !x->p_tv.heap;
   const uint32_t *da = (const uint32_t *)x->h_a.p, *db = need_b ? (const uint32_t *)x->h_b.p : nullptr;
   const uint32_t *dtv0 = has_tv ? (const uint32_t *)x->h_tv.p : nullptr;
   if (zc) {

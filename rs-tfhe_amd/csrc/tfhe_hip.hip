@@ -121,6 +121,7 @@ struct DevBuf {
 struct PinBuf {  // pinned host arena (hipHostMalloc)
   void *p = nullptr;
   size_t cap = 0;
+  bool heap = false;  // front-end lanes only: pinned memory was not to be had, this is ordinary memory (copies still work)
 };
 
 }  // namespace
@@ -937,7 +938,9 @@ int mux_dev(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, 
 // pipelined pageable copy (one thread cannot memcpy 550 MB faster than that).
 int ensure_pinned(tfhe_hip_ctx *ctx, PinBuf &b, size_t bytes) {
   if (bytes <= b.cap) return TFHE_HIP_OK;
-  if (b.p) HIPCHK(ctx, hipHostFree(b.p));
+  if (b.p && b.heap) free(b.p);
+  else if (b.p) HIPCHK(ctx, hipHostFree(b.p));
+  b.heap = false;
   b.p = nullptr;
   b.cap = 0;
   const size_t want = bytes + bytes / 4;
@@ -1231,6 +1234,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
 #ifdef TFHE_EXPERIMENT
   if (const char *env = getenv("TFHE_HIP_COMBINE_LANES")) ctx->comb->nlanes = std::max(1, std::min((int)Combiner::kLanes, atoi(env)));
   if (const char *env = getenv("TFHE_HIP_COMBINE_ZEROCOPY")) ctx->comb->zero_copy_in = atoi(env) != 0;
+  if (const char *env = getenv("TFHE_HIP_COMBINE_HEAP")) g_comb_force_heap = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_LANE_PRIORITY")) ctx->comb->lane_high_priority = atoi(env) != 0;
   if (const char *env = getenv("TFHE_HIP_LINGER_WINDOW_US")) ctx->comb->linger_window_us = atol(env);
   if (const char *env = getenv("TFHE_HIP_LINGER_QUIET_US")) ctx->comb->linger_quiet_us = atol(env);
@@ -1295,7 +1299,7 @@ void tfhe_hip_ctx_destroy(tfhe_hip_ctx *ctx) {
     if (b->p) (void)hipFree(b->p);
   free_key(ctx->own);
   for (PinBuf *b : {&ctx->p_a, &ctx->p_b, &ctx->p_c, &ctx->p_out, &ctx->p_tv, &ctx->p_idx})
-    if (b->p) (void)hipHostFree(b->p);
+    if (b->p) b->heap ? free(b->p) : (void)hipHostFree(b->p);
   if (ctx->d_tw) (void)hipFree(ctx->d_tw);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
