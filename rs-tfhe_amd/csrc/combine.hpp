@@ -45,6 +45,10 @@ struct CombReq : combq::Node {
   const uint32_t *testvec = nullptr;  // CB_GATES: NULL = the key's own
   int per_ct = 0;
   uint32_t *out = nullptr;
+  // CB_GATES with gate == COPY: bootstrap ca * a + cb * b, [n] += cconst (tfhe_hip_batch_lincomb_bootstrap); the
+  // combination is formed on the device, in the packed rows, ahead of the merged launch
+  bool lin = false;
+  uint32_t lin_ca = 1, lin_cb = 0, lin_cconst = 0;
   int rc = TFHE_HIP_OK;
   std::string err;
 };
@@ -105,6 +109,13 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
         GatePrep q;
         if (gate_prep(code, q) && q.cb) need_b = true;
       }
+  bool any_lin = false;  // requests whose rows are a linear combination still to be formed (k_tlwe_lincomb, on the device)
+  if (!mux)
+    for (const CombReq *r : g)
+      if (r->lin) {
+        any_lin = true;
+        if (r->lin_cb) need_b = true;
+      }
   // pack: every request's rows behind one another
   CHK(comb_arena(x, x->p_a, x->h_a, m * wb));
   if (need_b) CHK(comb_arena(x, x->p_b, x->h_b, m * wb));
@@ -131,7 +142,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
   const auto t_packed = std::chrono::steady_clock::now();
   // gate groups read each operand row once, in the blind rotation's prologue: with zero_copy_in the kernel takes the
   // pinned arena as it is (no copy to wait for ahead of the launch); mux reads its operands in three launches: copied
-  const bool zc = zero_copy_in && !mux && !x->p_a.heap && !x->p_b.heap && !x->p_tv.heap;
+  const bool zc = zero_copy_in && !mux && !any_lin && !x->p_a.heap && !x->p_b.heap && !x->p_tv.heap;
   const uint32_t *da = (const uint32_t *)x->h_a.p, *db = need_b ? (const uint32_t *)x->h_b.p : nullptr;
   const uint32_t *dtv0 = has_tv ? (const uint32_t *)x->h_tv.p : nullptr;
   if (zc) {
@@ -146,6 +157,23 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
     if (has_tv) HIPCHK(x, hipMemcpyAsync(x->h_tv.p, x->p_tv.p, m * (size_t)2 * kN * 4, hipMemcpyHostToDevice, s));
   }
   if (!mux && !uniform) HIPCHK(x, hipMemcpyAsync(x->h_idx.p, x->p_idx.p, m, hipMemcpyHostToDevice, s));
+  if (any_lin) {  // one streaming launch per run of requests with the same coefficients, in place in the packed rows
+    size_t at = 0;
+    for (size_t i = 0; i < g.size();) {
+      const CombReq *r = g[i];
+      size_t rows = r->count, j = i + 1;
+      if (r->lin) {
+        while (j < g.size() && g[j]->lin && g[j]->lin_ca == r->lin_ca && g[j]->lin_cb == r->lin_cb && g[j]->lin_cconst == r->lin_cconst) rows += g[j++]->count;
+        const size_t total = rows * w;
+        uint32_t *pa = (uint32_t *)x->h_a.p + at * w;
+        hipLaunchKernelGGL(k_tlwe_lincomb, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, r->lin_ca, pa, r->lin_cb,
+                           r->lin_cb ? (const uint32_t *)x->h_b.p + at * w : nullptr, r->lin_cconst, pa, (uint32_t)w, total);
+        HIPCHK(x, hipGetLastError());
+      }
+      at += rows;
+      i = j;
+    }
+  }
   uint32_t *dout = (uint32_t *)x->h_out.p;
   if (mux) {
     CHK(mux_dev(x, r0.cls == CB_MUX_NAIVE, da, db, (const uint32_t *)x->h_c.p, dout, m, s));

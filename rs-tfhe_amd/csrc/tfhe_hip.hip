@@ -1668,7 +1668,7 @@ namespace {
     return (code);                      \
   } while (0)
 int comb_gate_call(tfhe_hip_ctx *ctx, int gate, const uint8_t *codes, int keyswitch, const uint32_t *a, const uint32_t *b,
-                   const uint32_t *testvec, int per_ct, uint32_t *out, size_t count) {
+                   const uint32_t *testvec, int per_ct, uint32_t *out, size_t count, const GatePrep *lin = nullptr) {
   tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
   if (!ctx->own.key_loaded) COMB_FAIL(base, TFHE_HIP_ENOKEY, "cloud key not loaded");
   if (codes) {
@@ -1694,6 +1694,12 @@ int comb_gate_call(tfhe_hip_ctx *ctx, int gate, const uint8_t *codes, int keyswi
   r.per_ct = per_ct;
   r.out = out;
   r.count = count;
+  if (lin) {
+    r.lin = true;
+    r.lin_ca = lin->ca;
+    r.lin_cb = lin->cb;
+    r.lin_cconst = lin->cconst;
+  }
   return comb_submit(base, r);
 }
 int comb_mux_call(tfhe_hip_ctx *ctx, int naive, const uint32_t *a, const uint32_t *b, const uint32_t *c, uint32_t *out,
@@ -1845,17 +1851,10 @@ int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint3
                                      int per_ct, int keyswitch, uint32_t *out, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
   if (comb_takes(ctx, count) && a && out && (!cb || b)) {
-    // small call: the linear combination (wrapping u32 arithmetic, the words k_tlwe_lincomb / the kernels' prologue
-    // compute) is formed here by the caller, and the bootstrap of it joins the merged launches as a plain COPY
-    const size_t w = (size_t)(ctx->parent ? ctx->parent : ctx)->P.n + 1;
-    std::vector<uint32_t> prep(count * w);
-    for (size_t i = 0; i < count * w; ++i) {
-      uint32_t v = ca * a[i];
-      if (cb) v += cb * b[i];
-      if (i % w == w - 1) v += cconst;
-      prep[i] = v;
-    }
-    return comb_gate_call(ctx, TFHE_HIP_COPY, nullptr, keyswitch != 0, prep.data(), nullptr, testvec, per_ct, out, count);
+    // small call: it joins the merged launches as a COPY bootstrap whose rows are formed on the device first
+    // (k_tlwe_lincomb over the packed rows, one launch per run of requests with the same coefficients)
+    const GatePrep lin{ca, cb, cconst};
+    return comb_gate_call(ctx, TFHE_HIP_COPY, nullptr, keyswitch != 0, a, cb ? b : nullptr, testvec, per_ct, out, count, &lin);
   }
   ENTER(ctx);
   CHK(need_key(ctx));
