@@ -276,3 +276,57 @@ def test_small_calls_beside_a_large_one_and_a_key_reload(O, eng128, keys128):
     a2 = sk2.encrypt_bool(np.array([1, 0], bool), 6204)
     assert np.array_equal(view.batch_gate(O.GATE_NAND, a2, a2), O.batch_gate(ck2, O.GATE_NAND, a2, a2))
     view.close()
+
+
+@pytest.mark.parametrize("setname", ["SECURITY_UINT4", "SECURITY_80_BIT", "SECURITY_UINT1"])
+def test_merged_calls_on_other_parameter_sets(O, setname):
+    """The front end on the other instantiations: SECURITY_UINT4 (l = 1, general rounding, the base-32 key switch: per-call
+    lookup tables at message modulus 16), SECURITY_80_BIT (n = 550: gates and both mux forms) and SECURITY_UINT1 (l = 2).  A
+    merged launch runs the same kernels in the same operation order as one plain batch call of the same ciphertexts, so the
+    bits must be those of the batch call (which the parity suite holds to the CPU path), whatever the rounding regime;
+    and they decrypt."""
+    import rs_tfhe_amd as R
+    from conftest import oracle_keys
+    from rs_tfhe_amd import callers
+
+    sk, ck = oracle_keys(O, getattr(O, setname), with_time=(setname == "SECURITY_UINT4"))
+    pk = _cloud_key(ck)
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    rng = np.random.default_rng(606)
+    T, K = 24, 4
+    n = T * K
+    if setname == "SECURITY_UINT4":
+        msgs = rng.integers(0, 16, n)
+        cts = sk.encrypt_lwe_message(msgs, 16, 6301)
+        fs = (lambda x: x % 16, lambda x: (x * x) % 16, lambda x: (15 - x) % 16)
+        which = rng.integers(0, 3, n)
+        tables = [R.lut.Generator(16).generate_lookup_table(f).poly for f in fs]
+        tvs = np.stack([tables[w] for w in which])
+        eng.set_combining(0)
+        want = eng.batch_bootstrap(cts, tvs)  # one plain batch call, per-ciphertext tables
+        eng.set_combining(256)
+        eng.combine_stats()
+        out, _, _ = callers.run(eng, callers.OP_BOOTSTRAP_LUT, cts, testvecs=tvs, threads=T, calls=K)
+        st = eng.combine_stats()
+        assert np.array_equal(out, want)
+        assert np.array_equal(sk.decrypt_lwe_message(out, 16), np.array([fs[w](int(m)) for w, m in zip(which, msgs)]))
+    else:
+        A, B, Cc = (rng.integers(0, 2, n).astype(bool) for _ in range(3))
+        ca, cb, cc = sk.encrypt_bool(A, 6302), sk.encrypt_bool(B, 6303), sk.encrypt_bool(Cc, 6304)
+        gates = rng.integers(0, 10, n).astype(np.uint8)
+        naive = (np.arange(n) % 2).astype(np.uint8)
+        eng.set_combining(0)
+        want_g = eng.batch_gates_mixed(gates, ca, cb)
+        want_m = np.where(naive[:, None] == 1, eng.batch_mux(ca, cb, cc, naive=True), eng.batch_mux(ca, cb, cc, naive=False))
+        eng.set_combining(256)
+        assert np.array_equal(want_g[:24], np.stack([O.batch_gate(ck, int(g), ca[i:i + 1], cb[i:i + 1])[0] for i, g in enumerate(gates[:24])]))
+        eng.combine_stats()
+        out_g, _, _ = callers.run(eng, callers.OP_GATE, ca, cb, gates=gates, threads=T, calls=K)
+        out_m, _, _ = callers.run(eng, callers.OP_MUX, ca, cb, cc, gates=naive, threads=T, calls=K)
+        st = eng.combine_stats()
+        assert np.array_equal(out_g, want_g) and np.array_equal(out_m, want_m)
+        idx = np.nonzero(naive == 1)[0]
+        assert np.array_equal(sk.decrypt_bool(out_m[idx]), np.where(A[idx], B[idx], Cc[idx]))
+    assert st["launches"] * 3 <= st["requests"], st  # merged, not one by one
+    eng.close()
