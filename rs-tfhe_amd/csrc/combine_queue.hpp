@@ -61,6 +61,7 @@ struct Queue {
   std::atomic<size_t> pending{0};       // units queued or in flight
   std::atomic<uint64_t> arrivals{0};    // requests ever queued (the lingering leader watches it grow)
   std::atomic<uint64_t> taken{0};       // requests ever taken by a leader
+  std::atomic<int64_t> last_arrival_ns{0};  // when the last request was queued (bulk launches yield while small calls are arriving)
   // The last leader round that completed: how many callers it knew of -- the requests it carried PLUS those already
   // waiting behind it when it finished (in a closed loop that is the whole team: a leader that waited only for as many
   // as the last round carried settles at a part of the team and leaves the rest a launch behind, measured: 165 of 256
@@ -179,6 +180,7 @@ struct Queue {
       while (!arrivals_head.compare_exchange_weak(h, &r, std::memory_order_release, std::memory_order_relaxed));
     }
     arrivals.fetch_add(1, std::memory_order_relaxed);
+    last_arrival_ns.store(now_ns(), std::memory_order_relaxed);
     for (;;) {
       const uint32_t e = epoch.load(std::memory_order_seq_cst);  // (before the checks: a wake-up in between is not lost)
       const uint32_t st = r.state.load(std::memory_order_acquire);

@@ -311,6 +311,17 @@ int record_end(tfhe_hip_ctx *ctx, hipStream_t s, std::vector<std::pair<hipEvent_
   return TFHE_HIP_OK;
 }
 
+// Small calls are arriving at this context's front end (combine.hpp; defined after it): bulk launches then go out in
+// chunks, so that a merged launch waits for a chunk boundary and not for the whole batch.
+bool comb_interactive(const tfhe_hip_ctx *ctx);
+// A one-ciphertext call made while a 65,536-ciphertext launch holds every CU waits for all of it (median 13 ms, p90 308 ms:
+// the latency kernel's workgroup needs a whole CU and the batch kernel refills every slot the moment it frees; stream
+// priority changes nothing).  Cut into launches of 8,192 ciphertexts the batch costs 1.7 % more (190.6 vs 193.9 k
+// bootstraps/s) and the small call waits 39 ms in the median, 50 ms at p90 (16,384: 0.6 %, 70 / 90 ms; 4,096: 5 %, 19 / 23 ms
+// -- profiles/exp/logs/r6r_bulk_chunks.log).  Done only while small calls have arrived within the last 250 ms.
+constexpr size_t kYieldChunk = 8192;
+constexpr int64_t kYieldWindowNs = 250 * 1000 * 1000;
+
 typedef void (*br_kernel_t)(BlindRotateArgs);
 #if defined(TFHE_EXPERIMENT) && defined(TFHE_EXP_L1)  // the three-waves-per-SIMD l = 1 experiment (profiles/exp/superseded/blind_rotate_l1.hpp)
 bool br_is_l1(const tfhe_hip_ctx *ctx) { return ctx->P.l == 1; }
@@ -535,6 +546,7 @@ int launch_blind_rotate(tfhe_hip_ctx *ctx, hipStream_t s, const uint32_t *in_a, 
         const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, br_kernel(ctx), 64 * br_waves(ctx), lds);
         if (e == hipSuccess && per_cu > 0 && ctx->num_cus > 0) chunk = (size_t)per_cu * ctx->num_cus * br_waves(ctx);
       }
+      if (ctx->br_chunk == 0 && m_all >= 2 * kYieldChunk && comb_interactive(ctx)) chunk = kYieldChunk;
       if (chunk == 0 || chunk > m_all) chunk = m_all;
       for (size_t done = 0; done < m_all; done += chunk) {
         const size_t m = (m_all - done < chunk) ? m_all - done : chunk;
@@ -1024,6 +1036,15 @@ T *pinned_view(T *p, size_t bytes) {
 }  // namespace
 
 #include "combine.hpp"
+
+namespace {
+bool comb_interactive(const tfhe_hip_ctx *ctx) {
+  const Combiner *C = ctx->comb;
+  if (!C || C->max_count.load(std::memory_order_relaxed) == 0) return false;
+  const int64_t t = C->last_arrival_ns.load(std::memory_order_relaxed);
+  return t != 0 && combq::now_ns() - t < kYieldWindowNs;
+}
+}  // namespace
 
 // =============================================================================
 // C ABI

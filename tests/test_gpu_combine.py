@@ -330,3 +330,57 @@ def test_merged_calls_on_other_parameter_sets(O, setname):
         assert np.array_equal(sk.decrypt_bool(out_m[idx]), np.where(A[idx], B[idx], Cc[idx]))
     assert st["launches"] * 3 <= st["requests"], st  # merged, not one by one
     eng.close()
+
+
+def test_bulk_launches_yield_while_small_calls_arrive(O, eng128, keys128):
+    """A merged launch needs whole CUs and cannot start while a launch of tens of thousands of ciphertexts holds them all
+    (one-ciphertext calls beside 65,536-ciphertext batches: median 13 ms, p90 308 ms).  While small calls are arriving the
+    batch kernel of a large call goes out in launches of 8,192 ciphertexts (include/tfhe_hip.h): the same words, more
+    launches, and a small call waits for a chunk boundary.  Without small calls a batch is ONE launch."""
+    import time
+
+    import torch
+
+    sk, ck = keys128
+    rng = np.random.default_rng(607)
+    B = 32768
+    bits_a, bits_b = rng.integers(0, 2, B).astype(bool), rng.integers(0, 2, B).astype(bool)
+    ca, cb = sk.encrypt_bool(bits_a[:4096], 6401), sk.encrypt_bool(bits_b[:4096], 6402)
+    ca, cb = np.tile(ca, (8, 1)), np.tile(cb, (8, 1))
+    ta, tb = (torch.from_numpy(x.view(np.int32)).cuda() for x in (ca, cb))
+    quiet, busy = torch.empty_like(ta), torch.empty_like(ta)
+    time.sleep(0.3)  # nothing small has arrived for 250 ms: one launch
+    eng128.kernel_times()
+    eng128.set_profiling(True)
+    eng128.batch_gate_dev(O.GATE_NAND, ta, tb, quiet)
+    eng128.synchronize()
+    assert eng128.kernel_times()["blind_rotate_launches"] == 1
+    want1 = O.batch_gate(ck, O.GATE_NAND, ca[:1], cb[:1])
+    stop = threading.Event()
+    lat = []
+
+    def small():
+        while not stop.is_set():
+            t0 = time.perf_counter()
+            out = eng128.batch_gate(O.GATE_NAND, ca[:1], cb[:1])
+            lat.append((time.perf_counter() - t0) * 1e3)
+            assert np.array_equal(out, want1)
+            time.sleep(0.002)
+
+    th = threading.Thread(target=small)
+    th.start()
+    time.sleep(0.05)
+    eng128.kernel_times()
+    for _ in range(4):
+        eng128.batch_gate_dev(O.GATE_NAND, ta, tb, busy)
+        eng128.synchronize()
+    kt = eng128.kernel_times()
+    stop.set()
+    th.join()
+    eng128.set_profiling(False)
+    torch.cuda.synchronize()
+    assert np.array_equal(busy.cpu().numpy(), quiet.cpu().numpy())  # chunked or not: the same words
+    assert np.array_equal(quiet.cpu().numpy().view(np.uint32)[:64], O.batch_gate(ck, O.GATE_NAND, ca[:64], cb[:64]))
+    # 4 batches of 32,768 in chunks of 8,192 = 16 batch-kernel launches (+ the small calls' own one-workgroup launches)
+    assert kt["blind_rotate_launches"] >= 16, kt
+    print(f"small calls beside chunked 32,768-ciphertext batches: {len(lat)} calls, median {np.median(lat):.1f} ms, max {max(lat):.1f} ms")

@@ -722,7 +722,9 @@ def test_configs4_share_mux_and_xor_80bit(O, keys80):
     torch.cuda.synchronize()
     eng.set_profiling(False)
     kt = eng.kernel_times()
-    assert kt["blind_rotate_launches"] == 2 and kt["key_switch_launches"] == 1 and kt["bootstraps"] == 2 * M + M + X
+    # two blind-rotation launches (more only if small calls arrived on this context in the last 250 ms: bulk launches then
+    # go out in chunks, include/tfhe_hip.h) and one key switch
+    assert kt["blind_rotate_launches"] >= 2 and kt["key_switch_launches"] == 1 and kt["bootstraps"] == 2 * M + M + X
     mux, xor = mo.cpu().numpy().view(np.uint32), xo.cpu().numpy().view(np.uint32)
     # 640 mux outputs (3 bootstraps each on the CPU) and 1,024 xor outputs spread over each half vs the CPU path
     sl = np.unique(np.r_[0:24, np.linspace(0, M - 1, 592).astype(np.int64), M - 24:M])
