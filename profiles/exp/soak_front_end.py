@@ -35,11 +35,16 @@ gates = rng.integers(0, 10, M).astype(np.uint8)
 da, db, dc = (sk2.encrypt_bool(rng.integers(0, 2, 64).astype(bool), 3 + i) for i in range(3))
 tv = rng.integers(0, 2**32, (64, 2, N), dtype=np.uint64).astype(np.uint32)
 big_a, big_b = sk1.encrypt_bool(rng.integers(0, 2, 3000).astype(bool), 7), sk1.encrypt_bool(rng.integers(0, 2, 3000).astype(bool), 8)
+import torch  # noqa: E402
+
+bulk_a, bulk_b = (torch.from_numpy(np.tile(x, (7, 1)).view(np.int32)).cuda() for x in (big_a, big_b))  # 21,000: cut into chunks while small calls arrive
+bulk_out = torch.empty_like(bulk_a)
 eng.set_combining(0)  # the references: plain batch calls, front end off
 ref_gates = eng.batch_gates_mixed(gates, ca, cb)
 ref = {"mixed": v2.batch_gates_mixed(gates[:64], da, db), "boot": v2.batch_bootstrap(da), "boot_nks": v2.batch_bootstrap(da, keyswitch=False),
        "lut": v2.batch_bootstrap(da, tv), "mux": v2.batch_mux(da, db, dc, naive=False), "mux_naive": v2.batch_mux(da, db, dc, naive=True),
        "big": eng.batch_gate(0, big_a, big_b)}
+ref["bulk"] = np.tile(ref["big"], (7, 1))
 eng.set_combining(256)
 stop = time.time() + args.seconds
 bad, counts, lock = [], {}, threading.Lock()
@@ -86,6 +91,14 @@ def big():
         time.sleep(0.05)
 
 
+def bulk():
+    while time.time() < stop:
+        eng.batch_gate_dev(0, bulk_a, bulk_b, bulk_out)
+        eng.synchronize()
+        note("bulk_21000_dev", bool(np.array_equal(bulk_out.cpu().numpy().view(np.uint32), ref["bulk"])))
+        time.sleep(0.02)
+
+
 def reload():
     i = 0
     while time.time() < stop:
@@ -95,7 +108,7 @@ def reload():
         time.sleep(0.2)
 
 
-threads = [threading.Thread(target=team)] + [threading.Thread(target=small, args=(100 + i,)) for i in range(6)] + [threading.Thread(target=big), threading.Thread(target=reload)]
+threads = [threading.Thread(target=team)] + [threading.Thread(target=small, args=(100 + i,)) for i in range(6)] + [threading.Thread(target=big), threading.Thread(target=bulk), threading.Thread(target=reload)]
 for t in threads:
     t.start()
 for t in threads:
