@@ -384,3 +384,45 @@ def test_bulk_launches_yield_while_small_calls_arrive(O, eng128, keys128):
     # 4 batches of 32,768 in chunks of 8,192 = 16 batch-kernel launches (+ the small calls' own one-workgroup launches)
     assert kt["blind_rotate_launches"] >= 16, kt
     print(f"small calls beside chunked 32,768-ciphertext batches: {len(lat)} calls, median {np.median(lat):.1f} ms, max {max(lat):.1f} ms")
+
+
+def test_rounds_larger_than_one_launch_are_cut(O, eng128, keys128):
+    """A leader may take more than one launch holds (4,096 ciphertexts, the size of the lanes' arenas): 40 threads x 200
+    gates = 8,000 in flight, and -- with the bound raised to its maximum -- three calls of 3,000 at once.  The round is cut
+    into launches of whole requests; every caller still gets its own rows."""
+    from rs_tfhe_amd import callers
+
+    sk, ck = keys128
+    rng = np.random.default_rng(608)
+    T, K, per = 40, 2, 200
+    n = T * K * per
+    base_a = sk.encrypt_bool(rng.integers(0, 2, 2000).astype(bool), 6501)
+    base_b = sk.encrypt_bool(rng.integers(0, 2, 2000).astype(bool), 6502)
+    ca, cb = np.tile(base_a, (n // 2000, 1)), np.tile(base_b, (n // 2000, 1))
+    gates = rng.choice(np.array([O.GATE_NAND, O.GATE_XOR], np.uint8), T * K)
+    want = {int(g): eng128.batch_gates_mixed(np.full(2000, g, np.uint8), base_a, base_b) for g in np.unique(gates)}
+    assert np.array_equal(want[O.GATE_NAND][:48], O.batch_gate(ck, O.GATE_NAND, base_a[:48], base_b[:48]))
+    eng128.combine_stats()
+    out, _, _ = callers.run(eng128, callers.OP_GATE, ca, cb, gates=gates, threads=T, calls=K, per_call=per)
+    st = eng128.combine_stats()
+    for k in range(T * K):
+        rows = np.arange(k * per, (k + 1) * per)
+        assert np.array_equal(out[rows], want[int(gates[k])][rows % 2000]), k
+    assert st["requests"] == T * K and st["ciphertexts"] == n and st["launches"] >= 2
+    eng128.set_combining(4096)
+    try:
+        res = [None] * 3
+
+        def work(i):
+            res[i] = eng128.batch_gate(O.GATE_XOR, ca[i * 3000:(i + 1) * 3000], cb[i * 3000:(i + 1) * 3000])
+
+        ths = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        for i in range(3):
+            rows = np.arange(i * 3000, (i + 1) * 3000)
+            assert np.array_equal(res[i], want[O.GATE_XOR][rows % 2000]), i
+    finally:
+        eng128.set_combining(st["max_count"])
