@@ -26,12 +26,6 @@ int orc_tlwe_decrypt_lwe_message(const uint32_t *ct, int m, const uint32_t *key,
 typedef struct {
   orc_params P;
   uint32_t decomposition_offset;
-  const uint32_t *testvec, *bsk_time_unused_;
-  const double *bsk_fft;
-} orc_cloud_key_head_;  // (layout check only; the real struct follows)
-typedef struct {
-  orc_params P;
-  uint32_t decomposition_offset;
   const uint32_t *testvec;
   const double *bsk_fft;
   const uint32_t *bsk_time;
