@@ -38,6 +38,7 @@ int tfhe_callers_run(const tfhe_callers_api *api, void *handle, int is_pool, int
                      int threads, int calls, double *seconds, double *call_ms /* [threads * calls] or NULL */, char *err,
                      size_t errlen) {
   if (!api || !handle || !a || !out || threads < 1 || calls < 1 || per_call < 1) return TFHE_HIP_EINVAL;
+  if ((op == 0 && !gates) || (op == 2 && (!b || !c))) return TFHE_HIP_EINVAL;
   std::atomic<int> ready{0}, first_rc{0};
   std::atomic<bool> go{false};
   std::string first_text;
