@@ -67,3 +67,48 @@ def key_switch_phase_expected(params, lv1, key_lv1, prec_offset=None):
     trunc = abar & np.uint32((0xFFFFFFFF << (32 - bits)) & 0xFFFFFFFF)
     inner = (trunc * key_lv1.astype(np.uint32)[None, :]).sum(axis=1, dtype=np.uint32)
     return (lv1[:, N] - inner).astype(np.uint32)
+
+
+# ---- the composed bootstrap on TRIVIAL ciphertexts: a closed form that needs no key ---------------------------------------
+# blind_rotate (src/trgsw.rs:198-226) starts from X^b~ * testvec with b~ = 2N - ((b + 2^20) >> 21) (a non-wrapping add,
+# quirk Q2) and then walks the mask; for a == 0 every rotation amount is 0, every CMUX step decomposes the zero polynomial
+# (all digits 0, since the offset puts Bg/2 in every digit position) and leaves the accumulator alone -- EXACTLY, whatever
+# the key.  sample_extract_index_2(., 0) then carries coefficient 0 of X^b~ * testvec.b in its last word.  From
+# poly_mul_with_x_k (src/trgsw.rs:307-330), with r = (b + 2^20) >> 21 in [0, 2N]:
+#     r == 0 or r == 2N: p[0];    0 < r < N: p[r];    r == N: MAX - p[0];    N < r < 2N: MAX - p[r - N]   (quirk Q1)
+# For a lookup table of f at message modulus m (src/lut/generator.rs:89-137) and b = x / (2m) + delta, |delta| inside the
+# half-slot, that coefficient is encode(f(x)) = f64_to_torus((f(x) mod m) / (2m)) (src/lut/encoder.rs:66-73) -- except for
+# x = 0 and delta < 0, where the rotation wraps: the table's negated tail comes back through MAX - v = -v - 1, ONE LSB below
+# encode(f(0)).  This pins, through the real bootstrap entry points: b~ (Q2), the direction of the rotation, Q1, the
+# table's layout (slot width, half-slot offset, negated tail) and the encoder -- with no secret key and no noise.
+def trivial_ciphertexts(n, phases):
+    cts = np.zeros((len(phases), n + 1), np.uint32)
+    cts[:, n] = np.asarray(phases, np.uint64).astype(np.uint32)
+    return cts
+
+
+def lut_trivial_cases(f, m, margin=1 << 22):
+    """(phases, expected last words) for every message x of [0, m) at several places of its slot"""
+    phases, expect = [], []
+    half = (1 << 32) // (4 * m)  # half a slot, in torus units
+    for x in range(m):
+        centre = (x << 32) // (2 * m)
+        enc = ((int(f(x)) % m) << 32) // (2 * m)  # f64_to_torus(y / (2m)) for y < m: exact
+        for delta in (-(half - margin), -(half // 2), -1, 0, 1, half // 2, half - margin):
+            phase = (centre + delta) % (1 << 32)
+            phases.append(phase)
+            r = (phase + (1 << 20)) >> 21  # (phase just below 2^32 rounds to r = 2N: X^0, no wrap -- the non-wrapping add of Q2)
+            wraps = 1024 <= r < 2048
+            assert not wraps or (x == 0 and delta < 0)
+            expect.append((enc - 1) % (1 << 32) if wraps else enc)
+    return np.array(phases, np.uint64), np.array(expect, np.uint64).astype(np.uint32)
+
+
+def gate_testvec_trivial_cases():
+    """the cloud key's own test vector (b == 1/8 everywhere, src/key.rs:91-100): +1/8 where the rotation does not wrap,
+    MAX - 1/8 where it does"""
+    phases = np.array([0, 1, 1 << 20, (1 << 31) - (1 << 20) - 1, (1 << 31) - (1 << 20), 1 << 31, (3 << 30), (1 << 32) - (1 << 20) - 1,
+                       (1 << 32) - (1 << 20), (1 << 32) - 1], np.uint64)
+    r = (phases + (1 << 20)) >> 21
+    expect = np.where((r >= 1024) & (r < 2048), 0xFFFFFFFF - 0x20000000, 0x20000000).astype(np.uint32)
+    return phases, expect

@@ -60,3 +60,30 @@ def test_gpu_key_switch_exact_phase_under_a_noise_free_key(O, monkeypatch, setna
         assert np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1)), (setname, kernel, count, eng.describe_dispatch(count))
         assert not np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1, prec_offset=1 << (32 - bits)))
     eng.close()
+
+
+@pytest.mark.parametrize("setname,m", [("SECURITY_128_BIT", 2), ("SECURITY_128_BIT", 16), ("SECURITY_UINT4", 16), ("SECURITY_80_BIT", 4)])
+def test_gpu_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
+    """The fused GPU bootstrap (prologue, all n CMUX steps, extraction) without key switch on ciphertexts with a zero mask
+    returns the lookup table's entry for the phase EXACTLY, whatever the key (tests/closed_forms.py) -- through the batch
+    kernel, the latency kernels and the merged front end alike: b~ (Q2), the rotation's direction, MAX - x on the one slot
+    that wraps (Q1), the table's layout, the encoder; and the n CMUX steps of a zero rotation are the identity."""
+    import rs_tfhe_amd as R
+    from conftest import oracle_keys
+
+    sk, ck = oracle_keys(O, getattr(O, setname), with_time=(setname != "SECURITY_80_BIT"))
+    pk = _cloud_key(ck)
+    n = pk.params.n
+    eng = R.Engine(pk.params, 0)
+    eng.load_cloud_key(pk)
+    for f in (lambda x: x, lambda x: (x * x + 1) % m, lambda x: (m - 1 - x) % m):
+        phases, expect = CF.lut_trivial_cases(f, m)
+        lut = R.lut.Generator(m).generate_lookup_table(f).poly
+        cts = CF.trivial_ciphertexts(n, phases)
+        assert np.array_equal(eng.batch_bootstrap(cts, lut, keyswitch=False)[:, n], expect)  # small: the merged front end, latency kernel
+        reps = -(-1100 // len(cts))
+        big = np.tile(cts, (reps, 1))  # 1,100+: the batch kernel (+ a latency-kernel tail), the direct path
+        assert np.array_equal(eng.batch_bootstrap(big, lut, keyswitch=False)[:, n], np.tile(expect, reps))
+    phases, expect = CF.gate_testvec_trivial_cases()
+    assert np.array_equal(eng.batch_bootstrap(CF.trivial_ciphertexts(n, phases), keyswitch=False)[:, n], expect)
+    eng.close()

@@ -52,3 +52,21 @@ def test_key_switch_exact_phase_under_a_noise_free_key(O, setname, n):
     bits = P.basebit * P.t
     for wrong in (1 << (32 - bits), 1 << (32 - (2 + bits)), 0):
         assert not np.array_equal(got, CF.key_switch_phase_expected(P, lv1, sk.key_lv1, prec_offset=wrong))
+
+
+@pytest.mark.parametrize("setname,m", [("SECURITY_128_BIT", 2), ("SECURITY_128_BIT", 16), ("SECURITY_UINT4", 16)])
+def test_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
+    """The composed bootstrap without key switch (vanilla.rs:54-63, lut.rs:79-99) on ciphertexts with a zero mask returns
+    the lookup table's entry for the phase EXACTLY, whatever the key (tests/closed_forms.py): the initial rotation, its
+    direction, the MAX - x quirk on the one slot that wraps, the table's layout and the encoder in one identity."""
+    from conftest import oracle_keys
+
+    sk, ck = oracle_keys(O, getattr(O, setname), with_time=True)
+    n = ck.params.n
+    for f in (lambda x: x, lambda x: (x * x + 1) % m, lambda x: (m - 1 - x) % m):
+        phases, expect = CF.lut_trivial_cases(f, m)
+        out = O.batch_bootstrap(ck, CF.trivial_ciphertexts(n, phases), testvec=O.lut_generate(f, m), keyswitch=False)
+        assert np.array_equal(out[:, n], expect)
+    phases, expect = CF.gate_testvec_trivial_cases()
+    out = O.batch_bootstrap(ck, CF.trivial_ciphertexts(n, phases), keyswitch=False)
+    assert np.array_equal(out[:, n], expect)
