@@ -112,3 +112,29 @@ def gate_testvec_trivial_cases():
     r = (phases + (1 << 20)) >> 21
     expect = np.where((r >= 1024) & (r < 2048), 0xFFFFFFFF - 0x20000000, 0x20000000).astype(np.uint32)
     return phases, expect
+
+
+# ---- gate prep through the composed bootstrap, no key ------------------------------------------------------------------------
+# The linear forms of src/gates.rs:54-150 (read off the reference: coefficient of a, coefficient of b, constant in eighths of
+# the torus).  On trivial inputs (zero masks, phases pa / pb) the prepared sample is trivial with phase ca*pa + cb*pb + cc, and
+# the bootstrap without key switch under the cloud key's own test vector returns +1/8 where the rotation does not wrap and
+# MAX - 1/8 where it does (gate_testvec_trivial_cases above): every sample is one exact constraint on (ca, cb, cc).
+GATE_FORMS = {  # tfhe_hip_gate code -> (ca, cb, cc / 2^29)
+    0: (-1, -1, +1),  # nand   gates.rs:54-58    -(a + b) + 1/8
+    1: (+1, +1, +1),  # or     :62-66             a + b + 1/8
+    2: (+1, +1, -1),  # and    :70-74             a + b - 1/8
+    3: (+1, +2, +2),  # xor    :78-82             a + 2b + 1/4
+    4: (+1, -2, -2),  # xnor   :86-90             a - 2b - 1/4
+    5: (-1, -1, -1),  # nor    :94-98            -(a + b) - 1/8
+    6: (-1, +1, -1),  # and_ny :102-111          -a + b - 1/8
+    7: (+1, -1, -1),  # and_yn :115-124           a - b - 1/8
+    8: (-1, +1, +1),  # or_ny  :128-137          -a + b + 1/8
+    9: (+1, -1, +1),  # or_yn  :141-150           a - b + 1/8
+}
+
+
+def gate_trivial_expected(gate, pa, pb):
+    ca, cb, cc = GATE_FORMS[int(gate)]
+    phase = (ca * pa.astype(np.int64) + cb * pb.astype(np.int64) + cc * (1 << 29)) % (1 << 32)
+    r = (phase + (1 << 20)) >> 21
+    return np.where((r >= 1024) & (r < 2048), 0xFFFFFFFF - 0x20000000, 0x20000000).astype(np.uint32)

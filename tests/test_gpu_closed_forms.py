@@ -87,3 +87,26 @@ def test_gpu_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
     phases, expect = CF.gate_testvec_trivial_cases()
     assert np.array_equal(eng.batch_bootstrap(CF.trivial_ciphertexts(n, phases), keyswitch=False)[:, n], expect)
     eng.close()
+
+
+def test_gpu_gate_prep_on_trivial_inputs_is_the_linear_form_of_gates_rs(O, eng128, keys128):
+    """The gate prep fused into the blind rotation's prologue (kGateCa / Cb / Cc) against the linear forms of gates.rs:54-150,
+    with no key and no noise: trivial inputs with random phases through tfhe_hip_batch_gates_mixed_nks (per-ciphertext gate
+    codes, bootstrap without key switch) -- 400 exact constraints per gate; once merged (small call) and once as a batch."""
+    n = eng128.params.n
+    rng = np.random.default_rng(46)
+    pa, pb = rng.integers(0, 2**32, 4000, dtype=np.uint64), rng.integers(0, 2**32, 4000, dtype=np.uint64)
+    codes = (np.arange(4000) % 10).astype(np.uint8)
+    a, b = CF.trivial_ciphertexts(n, pa), CF.trivial_ciphertexts(n, pb)
+    exp = np.empty(4000, np.uint32)
+    for g in range(10):
+        exp[codes == g] = CF.gate_trivial_expected(g, pa[codes == g], pb[codes == g])
+    out = eng128.batch_gates_mixed(codes, a, b, keyswitch=False)  # 4,000: the batch kernel + a tail
+    assert np.array_equal(out[:, n], exp)
+    out = eng128.batch_gates_mixed(codes[:200], a[:200], b[:200], keyswitch=False)  # 200: the merged front end
+    assert np.array_equal(out[:, n], exp[:200])
+    for g in (0, 3, 4):  # and the one-gate entry point with the key switch: the result must at least decrypt like the closed form
+        got = eng128.batch_gate(g, a[:64], b[:64])
+        want = CF.gate_trivial_expected(g, pa[:64], pb[:64])
+        sk, _ = keys128
+        assert np.array_equal(sk.decrypt_bool(got), want == 0x20000000), g

@@ -70,3 +70,18 @@ def test_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
     phases, expect = CF.gate_testvec_trivial_cases()
     out = O.batch_bootstrap(ck, CF.trivial_ciphertexts(n, phases), keyswitch=False)
     assert np.array_equal(out[:, n], expect)
+
+
+def test_gate_prep_on_trivial_inputs_is_the_linear_form_of_gates_rs(O, keys128):
+    """Every gate's linear prep (gates.rs:54-150) through the composed bootstrap without key switch on trivial inputs with
+    random phases: 400 exact constraints per gate on (coefficient of a, coefficient of b, constant), no key involved."""
+    sk, ck = keys128
+    n = ck.params.n
+    rng = np.random.default_rng(45)
+    pa, pb = rng.integers(0, 2**32, 400, dtype=np.uint64), rng.integers(0, 2**32, 400, dtype=np.uint64)
+    a, b = CF.trivial_ciphertexts(n, pa), CF.trivial_ciphertexts(n, pb)
+    for gate in range(10):
+        prep = np.stack([O.gate_prep(gate, x, y, n) for x, y in zip(a, b)])
+        assert not prep[:, :n].any()
+        out = O.batch_bootstrap(ck, prep, keyswitch=False)
+        assert np.array_equal(out[:, n], CF.gate_trivial_expected(gate, pa, pb)), gate
