@@ -38,8 +38,8 @@
  * Thread safety: a context may be used from several host threads (the
  * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23).  Concurrent SMALL
  * host-pointer calls (tfhe_hip_batch_gate / _gates_mixed[_nks] / _bootstrap /
- * _lincomb_bootstrap / _mux of up to #CUs ciphertexts, and their tfhe_hip_pool_*
- * forms) are MERGED: whatever
+ * _lincomb_bootstrap / _mux / _blind_rotate of up to #CUs ciphertexts, and their
+ * tfhe_hip_pool_* forms) are MERGED: whatever
  * calls arrive while a launch is running share the next one (one launch per key
  * view and operation class, per-ciphertext gate codes / test vectors), so T threads
  * that each evaluate one gate get T gates per launch time, not one -- what a Rayon
@@ -494,7 +494,7 @@ int tfhe_hip_pool_export_cloud_key(tfhe_hip_pool *pool, int member, double *bsk,
 /* The batched hot path over all members, HOST pointers: same arguments and semantics as the single-context host
  * entry points of the same name (gates.rs:352-547; gates.rs:157-199; bootstrap/{vanilla,lut}.rs; trgsw.rs:289-305;
  * tlwe.rs:129-214).  One host thread per shard; results land in the caller's output slice in input order.
- * Small calls (gate / gates_mixed[_nks] / bootstrap / lincomb_bootstrap / mux of at most the combining bound, see tfhe_hip_set_combining)
+ * Small calls (gate / gates_mixed[_nks] / bootstrap / lincomb_bootstrap / mux / blind_rotate of at most the combining bound, see tfhe_hip_set_combining)
  * made by concurrent threads do not queue on the pool: each goes to the member (one per distinct device) with the least
  * work queued and shares launches there with the other threads' calls. */
 int tfhe_hip_pool_batch_gate(tfhe_hip_pool *pool, int gate, const uint32_t *a, const uint32_t *b, uint32_t *out,

@@ -68,7 +68,7 @@ namespace {
 
 bool g_comb_force_heap = false;  // (experiment builds, TFHE_HIP_COMBINE_HEAP: take the no-pinned-memory path of the lanes' arenas)
 
-enum CombClass { CB_GATES = 0, CB_MUX = 1, CB_MUX_NAIVE = 2 };
+enum CombClass { CB_GATES = 0, CB_MUX = 1, CB_MUX_NAIVE = 2, CB_ROTATE = 3 };  // CB_ROTATE: trgsw::blind_rotate, the output is the TRLWE
 
 // a lane's staging pair for one operand: host arena (packed by the leader; pinned, or ordinary memory where pinned memory
 // is not to be had -- the copies work from either, only slower) -> device buffer
@@ -96,7 +96,9 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
   size_t m = 0;
   for (const CombReq *r : g) m += r->count;
   hipStream_t s = x->stream;
-  const bool mux = r0.cls != CB_GATES;
+  const bool mux = r0.cls == CB_MUX || r0.cls == CB_MUX_NAIVE;
+  const bool rotate = r0.cls == CB_ROTATE;  // (rows in: [n+1]; rows out: [2][N])
+  const size_t ow = rotate ? (size_t)2 * kN : w, owb = ow * 4;
   // which operands the launch reads; one gate throughout (`uniform`) needs no per-ciphertext codes
   const int gate0 = r0.codes ? (int)r0.codes[0] : r0.gate;
   bool need_b = mux, need_c = mux, uniform = !mux;
@@ -122,7 +124,7 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
   if (need_c) CHK(comb_arena(x, x->p_c, x->h_c, m * wb));
   if (has_tv) CHK(comb_arena(x, x->p_tv, x->h_tv, m * (size_t)2 * kN * 4));
   if (!mux && !uniform) CHK(comb_arena(x, x->p_idx, x->h_idx, m));
-  CHK(comb_arena(x, x->p_out, x->h_out, m * wb));
+  CHK(comb_arena(x, x->p_out, x->h_out, m * owb));
   {
     size_t at = 0;
     for (const CombReq *r : g) {
@@ -182,7 +184,9 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
     if (uniform) gate_prep(gate0, gp);
     const uint8_t *dcodes = uniform ? nullptr : (const uint8_t *)x->h_idx.p;
     const uint32_t *dtv = dtv0;
-    if (r0.keyswitch) {
+    if (rotate) {
+      CHK(launch_blind_rotate(x, s, da, nullptr, gp, dtv, 1, m, dout, nullptr, nullptr, nullptr));
+    } else if (r0.keyswitch) {
       CHK(claim_scratch(x, s));
       CHK(ensure(x, x->lv1, lv1_rows(m) * (size_t)(kN + 1) * 4));
       CHK(launch_blind_rotate(x, s, da, db, gp, dtv, 1, m, nullptr, (uint32_t *)x->lv1.p, nullptr, dcodes));
@@ -191,13 +195,13 @@ int comb_run_group(tfhe_hip_ctx *x, KeyState *key, const std::vector<CombReq *> 
       CHK(launch_blind_rotate(x, s, da, db, gp, dtv, 1, m, nullptr, nullptr, dout, dcodes));
     }
   }
-  HIPCHK(x, hipMemcpyAsync(x->p_out.p, x->h_out.p, m * wb, hipMemcpyDeviceToHost, s));
+  HIPCHK(x, hipMemcpyAsync(x->p_out.p, x->h_out.p, m * owb, hipMemcpyDeviceToHost, s));
   HIPCHK(x, hipStreamSynchronize(s));
   const auto t_synced = std::chrono::steady_clock::now();
   {
     size_t at = 0;
     for (CombReq *r : g) {
-      memcpy(r->out, (const uint32_t *)x->p_out.p + at * w, r->count * wb);
+      memcpy(r->out, (const uint32_t *)x->p_out.p + at * ow, r->count * owb);
       at += r->count;
     }
   }

@@ -956,6 +956,10 @@ int tfhe_hip_pool_batch_mux(tfhe_hip_pool *p, int naive, const uint32_t *a, cons
 
 int tfhe_hip_pool_batch_blind_rotate(tfhe_hip_pool *p, const uint32_t *in, const uint32_t *testvec, uint32_t *out_trlwe,
                                      size_t count) {
+  if (pool_small(p, count)) {
+    if (!in || !out_trlwe) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
+    return pool_small_call(p, [&](tfhe_hip_ctx *c) { return tfhe_hip_batch_blind_rotate(c, in, testvec, out_trlwe, count); });
+  }
   POOL_ENTER(p);
   if (count && (!in || !out_trlwe)) return pool_fail(p, TFHE_HIP_EINVAL, "null pointer");
   const size_t w = (size_t)p->ctxs[0]->P.n + 1;

@@ -1899,6 +1899,21 @@ int tfhe_hip_batch_lincomb_bootstrap(tfhe_hip_ctx *ctx, uint32_t ca, const uint3
 int tfhe_hip_batch_blind_rotate(tfhe_hip_ctx *ctx, const uint32_t *in, const uint32_t *testvec,
                                 uint32_t *out_trlwe, size_t count) {
   if (!ctx) return TFHE_HIP_EINVAL;
+  if (comb_takes(ctx, count) && in && out_trlwe) {  // small call: merged with the other threads' (combine.hpp)
+    tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
+    if (!ctx->own.key_loaded) {
+      err_slot(base->id) = "cloud key not loaded";
+      return TFHE_HIP_ENOKEY;
+    }
+    CombReq r;
+    r.key = &ctx->own;
+    r.cls = CB_ROTATE;
+    r.a = in;
+    r.testvec = testvec;
+    r.out = out_trlwe;
+    r.count = count;
+    return comb_submit(base, r);
+  }
   ENTER(ctx);
   CHK(need_key(ctx));
   if (count == 0) return TFHE_HIP_OK;

@@ -138,11 +138,11 @@ def test_every_kind_of_small_call_at_once_under_two_keys(O, eng128, keys128):
     v2.load_cloud_key(_cloud_key(ck2))
     rng = np.random.default_rng(604)
     jobs = []
-    for t in range(27):
+    for t in range(33):
         eng, s, k = (eng128, sk, ck) if t % 2 == 0 else (v2, sk2, ck2)
         n = int(rng.integers(1, 9))
         a, b, c = (s.encrypt_bool(rng.integers(0, 2, n).astype(bool), 7000 + 3 * t + j) for j in range(3))
-        kind = t % 9
+        kind = t % 11
         if kind == 0:
             jobs.append((lambda e=eng, a=a, b=b: e.batch_gate(O.GATE_XOR, a, b), lambda k=k, a=a, b=b: O.batch_gate(k, O.GATE_XOR, a, b)))
         elif kind == 1:
@@ -164,6 +164,11 @@ def test_every_kind_of_small_call_at_once_under_two_keys(O, eng128, keys128):
             jobs.append((lambda e=eng, a=a, b=b, c=c: e.batch_mux(a, b, c, naive=False), lambda k=k, a=a, b=b, c=c: O.batch_mux(k, a, b, c, naive=False)))
         elif kind == 7:
             jobs.append((lambda e=eng, a=a, b=b, c=c: e.batch_mux(a, b, c, naive=True), lambda k=k, a=a, b=b, c=c: O.batch_mux(k, a, b, c, naive=True)))
+        elif kind == 9:  # trgsw::blind_rotate: the output is the TRLWE
+            jobs.append((lambda e=eng, a=a: e.batch_blind_rotate(a), lambda k=k, a=a: O.batch_blind_rotate(k, a)))
+        elif kind == 10:
+            tv = rng.integers(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
+            jobs.append((lambda e=eng, a=a, tv=tv: e.batch_blind_rotate(a, tv), lambda k=k, a=a, tv=tv: O.batch_blind_rotate(k, a, testvec=tv)))
         else:  # a linear combination bootstrapped through a table (tfhe_hip_batch_lincomb_bootstrap: formed by the caller, merged as COPY)
             tv = rng.integers(0, 2**32, (2, N), dtype=np.uint64).astype(np.uint32)
             prep = (np.uint32(3) * a + np.uint32(0xFFFFFFFE) * b).astype(np.uint32)
