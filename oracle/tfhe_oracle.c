@@ -22,9 +22,13 @@
  * golden vectors; this file is pinned against (i) the deterministic KAT inputs
  * of the reference's own tests with the exact schoolbook product as expected
  * value, (ii) the reference's SPQLIOS C++/asm negacyclic FFT compiled from
- * /root/reference into oracle/_ref/ (poly-mul cross check), (iii) the known
- * constants of the reference, (iv) decrypt-equality property tests that mirror
- * the reference's randomized unit tests.
+ * /root/reference into oracle/_ref/ (products, a whole external product, the
+ * rotation with its MAX - x quirk, a CMUX chain, sample_extract_index at every
+ * index), (iii) the known constants of the reference, (iv) decrypt-equality
+ * property tests that mirror the reference's randomized unit tests, (v) closed
+ * forms that need no key (tests/closed_forms.py): the key switch under a
+ * noise-free key, and trivial ciphertexts through the composed bootstrap (the
+ * lookup table's entry exactly; the ten gate preps as linear forms).
  */
 #include <math.h>
 #include <stdint.h>
