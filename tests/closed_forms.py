@@ -138,3 +138,21 @@ def gate_trivial_expected(gate, pa, pb):
     phase = (ca * pa.astype(np.int64) + cb * pb.astype(np.int64) + cc * (1 << 29)) % (1 << 32)
     r = (phase + (1 << 20)) >> 21
     return np.where((r >= 1024) & (r < 2048), 0xFFFFFFFF - 0x20000000, 0x20000000).astype(np.uint32)
+
+
+def trivial_mask_expected(n, phases):
+    """The first n words of the bootstrap-without-key-switch of trivial ciphertexts, for ANY test vector with a == 0:
+    X^b~ * 0 is MAX on the coefficients that wrap and 0 elsewhere (quirk Q1; poly_mul_with_x_k, trgsw.rs:307-330: k < N wraps
+    [0, k), N <= k < 2N wraps [k - N, N), k == 2N nothing), and sample_extract_index_2(., 0) (trlwe.rs:122-136, with its
+    N := n) reads p[0] = a[0], p[i] = MAX - a[n - i]."""
+    phases = np.asarray(phases, np.uint64)
+    k = 2 * N - ((phases + (1 << 20)) >> 21).astype(np.int64)  # b~ in [0, 2N]
+    j = np.arange(N)[None, :]
+    kk = k[:, None]
+    wrapped = np.where(kk < N, j < kk, (j >= kk - N) & (kk < 2 * N))
+    a_rot = np.where(wrapped, 0xFFFFFFFF, 0).astype(np.uint32)  # [count][N]
+    out = np.empty((len(phases), n), np.uint32)
+    out[:, 0] = a_rot[:, 0]
+    idx = n - np.arange(1, n)
+    out[:, 1:] = (np.uint32(0xFFFFFFFF) - a_rot[:, idx]).astype(np.uint32)
+    return out

@@ -80,10 +80,14 @@ def test_gpu_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
         phases, expect = CF.lut_trivial_cases(f, m)
         lut = R.lut.Generator(m).generate_lookup_table(f).poly
         cts = CF.trivial_ciphertexts(n, phases)
-        assert np.array_equal(eng.batch_bootstrap(cts, lut, keyswitch=False)[:, n], expect)  # small: the merged front end, latency kernel
+        out = eng.batch_bootstrap(cts, lut, keyswitch=False)  # small: the merged front end, latency kernel
+        assert np.array_equal(out[:, n], expect)
+        assert np.array_equal(out[:, :n], CF.trivial_mask_expected(n, phases))  # sample_extract_index_2 of the rotated zero mask
         reps = -(-1100 // len(cts))
         big = np.tile(cts, (reps, 1))  # 1,100+: the batch kernel (+ a latency-kernel tail), the direct path
-        assert np.array_equal(eng.batch_bootstrap(big, lut, keyswitch=False)[:, n], np.tile(expect, reps))
+        outb = eng.batch_bootstrap(big, lut, keyswitch=False)
+        assert np.array_equal(outb[:, n], np.tile(expect, reps))
+        assert np.array_equal(outb[:len(cts), :n], CF.trivial_mask_expected(n, phases))
     phases, expect = CF.gate_testvec_trivial_cases()
     assert np.array_equal(eng.batch_bootstrap(CF.trivial_ciphertexts(n, phases), keyswitch=False)[:, n], expect)
     eng.close()

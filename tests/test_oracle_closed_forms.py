@@ -67,6 +67,7 @@ def test_trivial_ciphertexts_read_the_table_exactly(O, setname, m):
         phases, expect = CF.lut_trivial_cases(f, m)
         out = O.batch_bootstrap(ck, CF.trivial_ciphertexts(n, phases), testvec=O.lut_generate(f, m), keyswitch=False)
         assert np.array_equal(out[:, n], expect)
+        assert np.array_equal(out[:, :n], CF.trivial_mask_expected(n, phases))  # sample_extract_index_2 of the rotated zero mask
     phases, expect = CF.gate_testvec_trivial_cases()
     out = O.batch_bootstrap(ck, CF.trivial_ciphertexts(n, phases), keyswitch=False)
     assert np.array_equal(out[:, n], expect)
