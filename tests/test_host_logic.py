@@ -61,6 +61,10 @@ def test_ctx_create_rejects_bad_params_without_gpu():
     assert b"unsupported" in lib.tfhe_hip_last_error(None)
     assert lib.tfhe_hip_ctx_create(None, 0, ctypes.byref(ctx)) == _capi.EINVAL
     lib.tfhe_hip_ctx_destroy(None)  # no-op
+    # the concurrent-callers controls: NULL handles are refused, nothing is dereferenced
+    st = _capi.CombineStats()
+    assert lib.tfhe_hip_set_combining(None, 64) == _capi.EINVAL
+    assert lib.tfhe_hip_get_combine_stats(None, ctypes.byref(st)) == _capi.EINVAL
 
 
 def test_kernel_selectors_are_validated_without_gpu(monkeypatch):
