@@ -1346,9 +1346,11 @@ tfhe_hip_ctx *tfhe_hip_key_parent(tfhe_hip_ctx *key) { return key ? (key->parent
 
 int tfhe_hip_key_is_loaded(tfhe_hip_ctx *ctx) {
   if (!ctx) return 0;
-  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
-  std::lock_guard<FairMutex> lk(base->mu);
-  return ctx->own.key_loaded ? 1 : 0;
+  // No lock: the host mirrors ask this before EVERY call (is the view's key resident yet?), and the context's mutex may
+  // be held for the length of a 65,536-ciphertext host call -- a one-gate call on another thread would wait 330 ms just to
+  // learn what it already knows.  The flag is set last by the calls that load a key and cleared first by those that
+  // change one; a caller that races its own key load is the caller's to order (as for any call under that key).
+  return __atomic_load_n(&ctx->own.key_loaded, __ATOMIC_ACQUIRE) ? 1 : 0;
 }
 
 int tfhe_hip_load_cloud_key(tfhe_hip_ctx *ctx, const double *bsk, const uint32_t *ksk,
@@ -2052,9 +2054,7 @@ int tfhe_hip_load_reenc_key(tfhe_hip_ctx *ctx, const uint32_t *key) {
 
 int tfhe_hip_reenc_key_is_loaded(tfhe_hip_ctx *ctx) {  // 0 / 1, never an error code (no device call is made)
   if (!ctx) return 0;
-  tfhe_hip_ctx *base = ctx->parent ? ctx->parent : ctx;
-  std::lock_guard<FairMutex> lk(base->mu);
-  return ctx->own.reenc_loaded ? 1 : 0;
+  return __atomic_load_n(&ctx->own.reenc_loaded, __ATOMIC_ACQUIRE) ? 1 : 0;  // (no lock: see tfhe_hip_key_is_loaded)
 }
 
 int tfhe_hip_batch_reencrypt_dev(tfhe_hip_ctx *ctx, const uint32_t *in, uint32_t *out, size_t count, void *stream) {
