@@ -38,7 +38,7 @@
  * Thread safety: a context may be used from several host threads (the
  * reference's `Bootstrap: Send + Sync`, src/bootstrap/mod.rs:23).  Concurrent SMALL
  * host-pointer calls (tfhe_hip_batch_gate / _gates_mixed[_nks] / _bootstrap /
- * _lincomb_bootstrap / _mux / _blind_rotate of up to #CUs ciphertexts, and their
+ * _lincomb_bootstrap / _mux / _blind_rotate of up to 2 x #CUs ciphertexts, and their
  * tfhe_hip_pool_* forms) are MERGED: whatever
  * calls arrive while a launch is running share the next one (one launch per key
  * view and operation class, per-ciphertext gate codes / test vectors), so T threads
@@ -348,8 +348,8 @@ int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
 /* Replaces: the concurrency a `Send + Sync` strategy gets from Rayon's workers (src/bootstrap/mod.rs:23-38,
  * src/parallel/rayon_impl.rs:40-47).  Host-pointer calls of at most `max_count` ciphertexts are merged with the calls
  * other threads make meanwhile (see "Thread safety" above); larger calls run alone, as before.  The default bound is
- * the device's CU count (one GPU runs that many ciphertexts in the time of one); 0 switches merging off, the largest
- * bound is 4096.  The environment variable TFHE_HIP_COMBINE (a number, 0 = off), read when a context is created,
+ * twice the device's CU count (512: what one launch of the latency kernels takes; a lone caller pays nothing up to
+ * there, concurrent callers of 512-gate calls gain 23 %); 0 switches merging off, the largest bound is 4096.  The environment variable TFHE_HIP_COMBINE (a number, 0 = off), read when a context is created,
  * sets the same bound.  Accepts a context or a key view (the setting is the context's).
  * Bulk work yields to small calls: a merged launch needs whole CUs and cannot start while a launch of tens of thousands
  * of ciphertexts holds them all, so while small calls have been arriving (within the last 250 ms) the batch kernel of a

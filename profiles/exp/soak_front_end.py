@@ -39,13 +39,14 @@ import torch  # noqa: E402
 
 bulk_a, bulk_b = (torch.from_numpy(np.tile(x, (7, 1)).view(np.int32)).cuda() for x in (big_a, big_b))  # 21,000: cut into chunks while small calls arrive
 bulk_out = torch.empty_like(bulk_a)
+bound = eng.combine_stats()["max_count"]
 eng.set_combining(0)  # the references: plain batch calls, front end off
 ref_gates = eng.batch_gates_mixed(gates, ca, cb)
 ref = {"mixed": v2.batch_gates_mixed(gates[:64], da, db), "boot": v2.batch_bootstrap(da), "boot_nks": v2.batch_bootstrap(da, keyswitch=False),
        "lut": v2.batch_bootstrap(da, tv), "mux": v2.batch_mux(da, db, dc, naive=False), "mux_naive": v2.batch_mux(da, db, dc, naive=True),
        "big": eng.batch_gate(0, big_a, big_b)}
 ref["bulk"] = np.tile(ref["big"], (7, 1))
-eng.set_combining(256)
+eng.set_combining(bound)
 stop = time.time() + args.seconds
 bad, counts, lock = [], {}, threading.Lock()
 

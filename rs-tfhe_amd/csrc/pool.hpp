@@ -779,7 +779,9 @@ void tfhe_hip_pool_shard(size_t count, int shard, int nshards, size_t *lo, size_
 // flight, where it shares launches with the other threads' calls.  (Key loads and device-resident calls keep the
 // pool's mutex; as for a context, changing a key while calls under it are in flight is the caller's to avoid.)
 namespace {
-inline bool pool_small(const tfhe_hip_pool *p, size_t count) { return p && !p->ctxs.empty() && comb_takes(p->ctxs[0], count); }
+// (up to 256 ciphertexts: beyond that a pool call is cut over several members, pool_world_for -- two devices run 512 in the
+// time one runs 256)
+inline bool pool_small(const tfhe_hip_pool *p, size_t count) { return p && !p->ctxs.empty() && count <= 256 && comb_takes(p->ctxs[0], count); }
 inline tfhe_hip_ctx *pool_least_loaded(tfhe_hip_pool *p) {
   // members that share a device count once (the first of them): two front ends on one GPU would launch on two streams that
   // need not overlap, and every call would wait for the other member's launch (measured on a pool of {0, 0}: 1.5 k gates/s

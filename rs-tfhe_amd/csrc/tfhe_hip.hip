@@ -1150,7 +1150,7 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
   ctx->num_cus = prop.multiProcessorCount;
-  const size_t combine_max = combine_env >= 0 ? (size_t)combine_env : (size_t)ctx->num_cus;
+  const size_t combine_max = combine_env >= 0 ? (size_t)combine_env : 2 * (size_t)ctx->num_cus;
   // pre-rounding magnitude bound: 2l polynomials x N terms x (Bg/2) digit x 2^31 key coefficient
   ctx->fast_round = std::log2(2.0 * p->l) + 10.0 + (p->bgbit - 1) + 31.0 < 51.0;
   // crossovers of the automatic dispatch, measured on the 256-CU part and kept as multiples of the CU count:
@@ -1247,8 +1247,10 @@ int tfhe_hip_ctx_create(const tfhe_hip_params *p, int device, tfhe_hip_ctx **out
   if ((e = hipMemcpy(ctx->d_tw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice)) != hipSuccess)
     return bail("hipMemcpy twiddles", e);
   // The combining front end (combine.hpp): host-pointer calls of up to `max_count` ciphertexts from concurrent threads
-  // share launches.  One device runs up to #CUs ciphertexts in the time of one (every ciphertext its own workgroup), so
-  // that is the default bound; TFHE_HIP_COMBINE=0 switches the front end off, any other number is the bound
+  // share launches.  Default bound: 2 x #CUs (what the pair kernel runs in one go).  Measured with calls of 512 / 1,024 /
+  // 4,096 gates (profiles/exp/logs/r7_combining_bound.log): merging them costs a LONE caller nothing at 512 (4.08 vs 4.16 ms),
+  // 2.6 % at 1,024 and 13 % at 4,096 (one thread packs 23 MB), and gives 8 concurrent callers +23 % at 512, +16 % at
+  // 1,024 and nothing at 4,096.  TFHE_HIP_COMBINE=0 switches the front end off, any other number is the bound
   // (tfhe_hip_set_combining changes it at run time).
   ctx->comb = new Combiner();
   ctx->comb->max_count = combine_max;

@@ -308,9 +308,10 @@ def test_merged_calls_on_other_parameter_sets(O, setname):
         which = rng.integers(0, 3, n)
         tables = [R.lut.Generator(16).generate_lookup_table(f).poly for f in fs]
         tvs = np.stack([tables[w] for w in which])
+        bound = eng.combine_stats()["max_count"]
         eng.set_combining(0)
         want = eng.batch_bootstrap(cts, tvs)  # one plain batch call, per-ciphertext tables
-        eng.set_combining(256)
+        eng.set_combining(bound)
         eng.combine_stats()
         out, _, _ = callers.run(eng, callers.OP_BOOTSTRAP_LUT, cts, testvecs=tvs, threads=T, calls=K)
         st = eng.combine_stats()
@@ -321,10 +322,11 @@ def test_merged_calls_on_other_parameter_sets(O, setname):
         ca, cb, cc = sk.encrypt_bool(A, 6302), sk.encrypt_bool(B, 6303), sk.encrypt_bool(Cc, 6304)
         gates = rng.integers(0, 10, n).astype(np.uint8)
         naive = (np.arange(n) % 2).astype(np.uint8)
+        bound = eng.combine_stats()["max_count"]
         eng.set_combining(0)
         want_g = eng.batch_gates_mixed(gates, ca, cb)
         want_m = np.where(naive[:, None] == 1, eng.batch_mux(ca, cb, cc, naive=True), eng.batch_mux(ca, cb, cc, naive=False))
-        eng.set_combining(256)
+        eng.set_combining(bound)
         assert np.array_equal(want_g[:24], np.stack([O.batch_gate(ck, int(g), ca[i:i + 1], cb[i:i + 1])[0] for i, g in enumerate(gates[:24])]))
         eng.combine_stats()
         out_g, _, _ = callers.run(eng, callers.OP_GATE, ca, cb, gates=gates, threads=T, calls=K)
