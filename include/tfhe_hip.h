@@ -349,8 +349,9 @@ int tfhe_hip_batch_poly_mul(tfhe_hip_ctx *ctx, uint32_t *res, const uint32_t *a,
  * src/parallel/rayon_impl.rs:40-47).  Host-pointer calls of at most `max_count` ciphertexts are merged with the calls
  * other threads make meanwhile (see "Thread safety" above); larger calls run alone, as before.  The default bound is
  * twice the device's CU count (512: what one launch of the latency kernels takes; a lone caller pays nothing up to
- * there, concurrent callers of 512-gate calls gain 23 %); 0 switches merging off, the largest bound is 4096.  The environment variable TFHE_HIP_COMBINE (a number, 0 = off), read when a context is created,
- * sets the same bound.  Accepts a context or a key view (the setting is the context's).
+ * there, concurrent callers of 512-gate calls gain 23 %); 0 switches merging off, the largest bound is 4096.  The
+ * environment variable TFHE_HIP_COMBINE (a number, 0 = off), read when a context is created, sets the same bound.
+ * Accepts a context or a key view (the setting is the context's).
  * Bulk work yields to small calls: a merged launch needs whole CUs and cannot start while a launch of tens of thousands
  * of ciphertexts holds them all, so while small calls have been arriving (within the last 250 ms) the batch kernel of a
  * large call on the same context goes out in launches of 8,192 ciphertexts -- a small call then waits for a chunk
