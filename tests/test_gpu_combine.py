@@ -108,6 +108,17 @@ def test_concurrent_single_gates_on_a_pool(O, eng128, keys128):
     for flag in (0, 1):
         idx = np.nonzero(naive == flag)[0]
         assert np.array_equal(outm[idx], O.batch_mux(ck, ca[idx], cb[idx], cc[idx], naive=bool(flag)))
+    # a key view of the pool (a second cloud key on every member): small calls under it merge on the same front end, in
+    # launches of their own
+    sk2, ck2 = O.keygen(O.SECURITY_128_BIT, 4321)
+    pv = pool.new_key_view()
+    pv.load_cloud_key(_cloud_key(ck2))
+    a2, b2 = sk2.encrypt_bool(A[:64], 6007), sk2.encrypt_bool(B[:64], 6008)
+    out2, _, _ = callers.run(pv, callers.OP_GATE, a2, b2, gates=gates[:64], threads=16, calls=4)
+    assert np.array_equal(out2, _oracle_gates(O, ck2, gates[:64], a2, b2))
+    out1, _, _ = callers.run(pool, callers.OP_GATE, ca[:64], cb[:64], gates=gates[:64], threads=16, calls=4)
+    assert np.array_equal(out1, out[:64])  # the pool's own key is still the one its calls run under
+    pv.close()
     pool.close()
     print(f"pool: {T * K / secs:.0f} gates/s, {st}")
 
