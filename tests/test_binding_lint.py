@@ -303,3 +303,41 @@ def test_rust_methods_and_fields_exist():
             if not name[0].isdigit():
                 problems.append(f"{os.path.relpath(f, ROOT)}: field `.{name}` is not a field of any struct of the crate or the binding")
     assert not problems, "\n".join(problems)
+
+
+def test_rust_repr_c_structs_match_the_header():
+    """Every `#[repr(C)] struct` with fields under rust/ against the C struct of the same fields in include/tfhe_hip.h: same
+    number of fields, same names in the same order, same widths.  (A by-value struct with a swapped or missing field is the
+    other thing rustc takes on faith.)  Opaque handles (`_private: [u8; 0]`) are skipped."""
+    c_text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "tfhe_hip.h")).read(), flags=re.S)
+    c_structs = {}
+    for m in re.finditer(r"typedef struct (\w+) \{(.*?)\} (\w+);", c_text, flags=re.S):
+        fields = []
+        for decl in m.group(2).split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            ctype, names = decl.rsplit(" ", 1)[0], decl.rsplit(" ", 1)[1]
+            # `double a, b;` declares several
+            parts = [p.strip() for p in decl[len(decl.split(" ")[0]) + 1:].split(",")] if "," in decl else [names]
+            base = decl.split(" ")[0] if "," in decl else ctype
+            for nme in parts:
+                fields.append((nme, {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "double": "f64", "int": "c_int",
+                                     "size_t": "usize"}.get(base, base)))
+        c_structs[m.group(3)] = fields
+    rust_text = "\n".join(open(f).read() for f in _rust_sources())
+    checked = 0
+    for m in re.finditer(r"#\[repr\(C\)\]\s*(?:pub\s+)?struct (\w+)\s*\{(.*?)\}", rust_text, flags=re.S):
+        name, body = m.group(1), m.group(2)
+        fields = [(f.split(":")[0].strip().replace("pub ", ""), f.split(":")[1].strip()) for f in body.split(",") if ":" in f]
+        if [f for f in fields if f[0] == "_private"]:
+            continue
+        # TfheHipParams -> tfhe_hip_params
+        cname = re.sub(r"(?<!^)(?=[A-Z])", "_", name).lower()
+        assert cname in c_structs, f"{name}: no struct {cname} in include/tfhe_hip.h"
+        want = c_structs[cname]
+        assert [f[0] for f in fields] == [w[0] for w in want], (name, fields, want)
+        for (fn, ft), (_, wt) in zip(fields, want):
+            assert ft == wt or {ft, wt} <= {"i32", "c_int"}, (name, fn, ft, wt)
+        checked += 1
+    assert checked >= 1
