@@ -341,3 +341,56 @@ def test_rust_repr_c_structs_match_the_header():
             assert ft == wt or {ft, wt} <= {"i32", "c_int"}, (name, fn, ft, wt)
         checked += 1
     assert checked >= 1
+
+
+def test_rust_sources_are_lexically_well_formed():
+    """No compiler here, so at least: in every .rs file under rust/ the brackets ( [ { balance and nest properly outside of
+    comments, string literals and character literals (lifetimes like `'a` are not character literals), and every
+    statement-level `let` / `fn` line that opens a block closes it -- the class of typo that would stop `cargo build` at
+    its first line of output."""
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for path in _rust_sources() + [os.path.join(ROOT, "rust", "tests", "hip_gates.rs")]:
+        text = open(path).read()
+        stack, i, n, line = [], 0, len(text), 1
+        while i < n:
+            c = text[i]
+            if c == "\n":
+                line += 1
+            if text.startswith("//", i):
+                i = text.find("\n", i)
+                i = n if i < 0 else i
+                continue
+            if text.startswith("/*", i):
+                j = text.find("*/", i + 2)
+                assert j >= 0, f"{path}:{line}: unterminated block comment"
+                line += text.count("\n", i, j)
+                i = j + 2
+                continue
+            if c == '"' or (c == "r" and text.startswith('r#"', i)) or (c == "b" and text.startswith('b"', i)):
+                if c == "r":
+                    j = text.find('"#', i + 3)
+                    assert j >= 0, f"{path}:{line}: unterminated raw string"
+                    line += text.count("\n", i, j)
+                    i = j + 2
+                    continue
+                j = i + (2 if c == "b" else 1)
+                while j < n and text[j] != '"':
+                    j += 2 if text[j] == "\\" else 1
+                assert j < n, f"{path}:{line}: unterminated string literal"
+                line += text.count("\n", i, j)
+                i = j + 1
+                continue
+            if c == "'":
+                m = re.match(r"'(\\.|[^\\'])'", text[i:i + 4])
+                if m:  # a character literal
+                    i += m.end()
+                    continue
+                i += 1  # a lifetime
+                continue
+            if c in "([{":
+                stack.append((c, line))
+            elif c in ")]}":
+                assert stack and stack[-1][0] == pairs[c], f"{os.path.relpath(path, ROOT)}:{line}: unmatched `{c}`" + (f" (open `{stack[-1][0]}` from line {stack[-1][1]})" if stack else "")
+                stack.pop()
+            i += 1
+        assert not stack, f"{os.path.relpath(path, ROOT)}: unclosed `{stack[-1][0]}` from line {stack[-1][1]}"
